@@ -1,0 +1,310 @@
+// f3ds_algo.h -- the data-parallel reformulation of the order-dependent parts of the path, as
+// per-element functions shared by the HIP kernels (f3ds_hip.hip) and by the sequential CPU
+// emulation used in the CPU test-suite (tests/emul/f3ds_emul.cpp).
+//
+// Three pieces of the reference are sequential as written and are restated here in a form whose
+// result is identical but whose evaluation is independent per element:
+//
+//  (1) seed grid growth   (PCL OctreePointCloud::adoptBoundingBoxToPoint):
+//      the cube only changes at a handful of "events"; a voxel's cell key is the key at its own
+//      insertion epoch plus the integer shifts of the later events.
+//  (2) label propagation  (PCL SupervoxelHelper::expand): helpers run in
+//      label order inside a sweep and see each other's steals (Gauss-Seidel).  With
+//      R(u) := "leaf u is still owned by its sweep-start owner when that owner's turn comes",
+//         R(w) = not exists u in N(w): owner0(u) < owner0(w), d(owner0(u), w) < dist0(w), R(u)
+//      (well-founded on the owner label), the state of voxel v after the sweep is obtained by
+//      offering v, in ascending label order, to every helper that owns an R-true leaf in N(v).
+//  (3) merge order        (std::multimap rebuild in Clustering::merge,
+//      /root/reference/src/clustering.cpp:431-468): the new map is filled in old-map order, so
+//      equal weights keep their previous relative order.  Map order is therefore the
+//      lexicographic order of (w_t, w_{t-1}, ..., w_0, initial index); an edge only needs the
+//      list of its own weight changes to be compared with any other edge.
+#ifndef F3DS_ALGO_H_
+#define F3DS_ALGO_H_
+
+#include "f3ds_numerics.h"
+
+namespace f3ds {
+
+// ---------------------------------------------------------------------------------------------
+// (1) seed grid
+// ---------------------------------------------------------------------------------------------
+#define F3DS_MAX_SEED_EVENTS 48
+struct SeedEvent {
+    int trigger;          // voxel index that caused the event
+    int depth;            // tree depth after the event
+    double min[3];        // cube minimum after the event
+    unsigned off[3];      // key shift accumulated up to and including this event
+};
+struct SeedGrid {
+    int n_events;
+    int error;
+    int defined;
+    int depth;
+    double res;
+    double min[3], max[3];
+    unsigned off[3];
+    SeedEvent ev[F3DS_MAX_SEED_EVENTS];
+};
+F3DS_HD void a_seed_init(SeedGrid& g, float seed_res) {
+    g.n_events = 0; g.error = 0; g.defined = 0; g.depth = 0; g.res = (double)seed_res;
+    for (int a = 0; a < 3; ++a) { g.min[a] = g.max[a] = 0.0; g.off[a] = 0u; }
+}
+F3DS_HD bool a_seed_violates(const SeedGrid& g, const float p[3]) {
+    if (!g.defined) return true;
+    for (int a = 0; a < 3; ++a)
+        if ((double)p[a] < g.min[a] || (double)p[a] >= g.max[a]) return true;
+    return false;
+}
+// a box given as (lo, hi) corners lies inside the cube iff both corners do
+F3DS_HD bool a_seed_box_violates(const SeedGrid& g, const float lo[3], const float hi[3]) {
+    return a_seed_violates(g, lo) || a_seed_violates(g, hi);
+}
+F3DS_HD void a_seed_push(SeedGrid& g, int trigger) {
+    if (g.n_events >= F3DS_MAX_SEED_EVENTS) { g.error = -4; return; }
+    SeedEvent& e = g.ev[g.n_events++];
+    e.trigger = trigger; e.depth = g.depth;
+    for (int a = 0; a < 3; ++a) { e.min[a] = g.min[a]; e.off[a] = g.off[a]; }
+}
+// make point `trigger` fit: adoptBoundingBoxToPoint's while(true) loop
+F3DS_HD void a_seed_grow(SeedGrid& g, int trigger, const float p[3]) {
+    const double eps = (double)F3DS_FLT_EPS;
+    while (!g.error) {
+        bool lo[3], up[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = (double)p[a] < g.min[a]; up[a] = (double)p[a] >= g.max[a]; }
+        if (!(lo[0] || lo[1] || lo[2] || up[0] || up[1] || up[2] || !g.defined)) break;
+        if (g.defined) {
+            double side = (double)(1u << g.depth) * g.res;
+            unsigned shift = 1u << g.depth;
+            for (int a = 0; a < 3; ++a)
+                if (!up[a]) { g.min[a] -= side; g.off[a] += shift; }   // old root becomes the upper child
+            g.depth++;
+            if (g.depth > 21) { g.error = -4; return; }
+            side = (double)(1u << g.depth) * g.res - eps;
+            for (int a = 0; a < 3; ++a) g.max[a] = g.min[a] + side;
+        } else {
+            GridInfo t;
+            t.res = g.res; t.error = 0;
+            for (int a = 0; a < 3; ++a) { t.min[a] = (double)p[a] - g.res / 2; t.max[a] = (double)p[a] + g.res / 2; }
+            n_key_bit_size(t);
+            if (t.error) { g.error = t.error; return; }
+            for (int a = 0; a < 3; ++a) { g.min[a] = t.min[a]; g.max[a] = t.max[a]; }
+            g.depth = t.depth;
+            g.defined = 1;
+        }
+        a_seed_push(g, trigger);
+    }
+}
+// final cell key of voxel i (after all events)
+F3DS_HD void a_seed_key(const SeedGrid& g, int i, const float p[3], unsigned key[3]) {
+    int e = 0;
+    for (int k = 0; k < g.n_events; ++k) if (g.ev[k].trigger <= i) e = k;
+    const SeedEvent& ev = g.ev[e];
+    for (int a = 0; a < 3; ++a)
+        key[a] = (unsigned)(((double)p[a] - ev.min[a]) / g.res) + (g.off[a] - ev.off[a]);
+}
+F3DS_HD void a_seed_centre(const SeedGrid& g, const unsigned key[3], float c[3]) {
+    for (int a = 0; a < 3; ++a) c[a] = (float)(((double)key[a] + 0.5f) * g.res + g.min[a]);
+}
+// flann::L2_Simple<float>
+F3DS_HD float a_sqdist(const float* a, const float* b) {
+    float r = 0.0f;
+    float d = a[0] - b[0]; r += d * d;
+    d = a[1] - b[1]; r += d * d;
+    d = a[2] - b[2]; r += d * d;
+    return r;
+}
+F3DS_HD float a_min_points(float seed_res, float voxel_res) {
+    float search_radius = 0.5f * seed_res;
+    return 0.05f * (search_radius) * (search_radius) * 3.1415926536f / (voxel_res * voxel_res);
+}
+F3DS_HD float a_radius_sq(float seed_res) {
+    float search_radius = 0.5f * seed_res;
+    return (float)((double)search_radius * (double)search_radius);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (2) label propagation sweep
+// ---------------------------------------------------------------------------------------------
+struct SweepView {
+    int V;
+    const int* nbr;           // V x 27, -1 = none
+    const float* vf;          // V x 12 voxel features: xyz rgb normal pad
+    const uint32_t* owner;    // V, sweep-start owner label (0 = none)
+    const float* dist;        // V, sweep-start VoxelData::distance_
+    const float* hc;          // (S0+1) x 12 helper centroid features, row = label
+    // "ghost" leaves: createSupervoxelHelpers puts the seed voxel into the helper's leaf set and
+    // overwrites owner_; when two seeds resolve to the same voxel the earlier helper keeps a leaf
+    // it does not own.  Such a leaf still expands and still counts in updateCentroid until the
+    // helper steals it for real.  ghost_head[v] = first helper (label) with an active ghost on v,
+    // ghost_next[label] chains further ones (0 ends the chain).
+    const uint32_t* ghost_head;   // V
+    const uint32_t* ghost_next;   // S0+1
+    float seed_res, w_normal, w_color, w_spatial;
+};
+F3DS_HD float a_helper_dist(const SweepView& s, uint32_t g, int v) {
+    return n_voxel_distance(s.hc + (size_t)g * 12, s.vf + (size_t)v * 12, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
+}
+#define F3DS_R_STACK 12
+// R(w) for an owned voxel w; *overflow is set when the dependency chain is deeper than the stack
+F3DS_HD bool a_eval_R(const SweepView& s, int w0, int* overflow) {
+    int node[F3DS_R_STACK];
+    int slot[F3DS_R_STACK];
+    int sp = 0;
+    node[0] = w0; slot[0] = 0;
+    for (;;) {
+        const int w = node[sp];
+        const uint32_t h = s.owner[w];
+        const float dw = s.dist[w];
+        bool pushed = false, stolen = false;
+        uint32_t g_cached = 0; bool cached_less = false;
+        for (int k = slot[sp]; k < 27; ++k) {
+            int u = s.nbr[(size_t)w * 27 + k];
+            if (u < 0) continue;
+            // a lower helper with a ghost leaf on u always reaches w at its turn
+            for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
+                if (gg < h && a_helper_dist(s, gg, w) < dw) { stolen = true; break; }
+            if (stolen) break;
+            uint32_t g = s.owner[u];
+            if (g == 0u || g >= h) continue;
+            if (g != g_cached) { g_cached = g; cached_less = a_helper_dist(s, g, w) < dw; }
+            if (!cached_less) continue;
+            // helper g would steal w through u, provided u is still g's at g's turn
+            slot[sp] = k + 1;
+            if (sp + 1 >= F3DS_R_STACK) { *overflow = 1; return true; }
+            ++sp; node[sp] = u; slot[sp] = 0;
+            pushed = true;
+            break;
+        }
+        if (pushed) continue;
+        bool r = !stolen;              // true: nobody steals node[sp] before its owner's turn
+        for (;;) {
+            if (sp == 0) return r;
+            --sp;
+            if (r) { r = false; continue; }   // child still owned -> parent stolen -> R(parent) = false
+            break;                     // child was stolen first -> parent keeps scanning
+        }
+    }
+}
+// state of voxel v after the sweep; ghost_done[g] is set when helper g turns its ghost leaf on v
+// into a real one (only the thread of v writes entries of helpers ghosting v)
+F3DS_HD void a_claim(const SweepView& s, const unsigned char* R, int v, uint32_t* owner_out, float* dist_out,
+                     unsigned char* ghost_done) {
+    uint32_t o = s.owner[v];
+    float d = s.dist[v];
+    uint32_t last = 0;
+    for (;;) {
+        uint32_t g = 0xFFFFFFFFu;     // smallest candidate label above `last`
+        for (int k = 0; k < 27; ++k) {
+            int u = s.nbr[(size_t)v * 27 + k];
+            if (u < 0) continue;
+            uint32_t gu = s.owner[u];
+            if (gu > last && gu < g && R[u]) g = gu;
+            for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
+                if (gg > last && gg < g) g = gg;
+        }
+        if (g == 0xFFFFFFFFu) break;
+        last = g;
+        if (g == o) continue;          // neighbor_voxel.owner_ == this
+        float dg = a_helper_dist(s, g, v);
+        if (dg < d) {
+            d = dg; o = g;
+            for (uint32_t gg = s.ghost_head[v]; gg != 0u; gg = s.ghost_next[gg])
+                if (gg == g) ghost_done[g] = 1;
+        }
+    }
+    *owner_out = o; *dist_out = d;
+}
+// SupervoxelHelper::updateCentroid from the ordered sums {xyz, rgb, normal xyz}
+F3DS_HD void a_centroid_finish(const float sum[9], unsigned count, float row[12]) {
+    float nx = sum[6], ny = sum[7], nz = sum[8];
+    float z = (nx * nx + ny * ny) + (nz * nz + 0.0f);
+    if (z > 0.0f) { float q = n_sqrtf(z); nx /= q; ny /= q; nz /= q; }
+    float c = (float)count;
+    row[0] = sum[0] / c; row[1] = sum[1] / c; row[2] = sum[2] / c;
+    row[3] = sum[3] / c; row[4] = sum[4] / c; row[5] = sum[5] / c;
+    row[6] = nx; row[7] = ny; row[8] = nz;
+    row[9] = row[10] = row[11] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (3) merge stage
+// ---------------------------------------------------------------------------------------------
+// payload row of one voxel inside a supervoxel: xx xy xz yy yz zz x y z r g b
+F3DS_HD void a_payload_row(const float* vf_row, float out[12]) {
+    float x = vf_row[0], y = vf_row[1], z = vf_row[2];
+    out[0] = x * x; out[1] = x * y; out[2] = x * z; out[3] = y * y; out[4] = y * z; out[5] = z * z;
+    out[6] = x; out[7] = y; out[8] = z;
+    // VoxelData::getPoint truncates the mean colour to 8 bits; mean_color reads it back as float
+    out[9] = (float)((uint32_t)vf_row[3] & 255u);
+    out[10] = (float)((uint32_t)vf_row[4] & 255u);
+    out[11] = (float)((uint32_t)vf_row[5] & 255u);
+}
+// one step of the ordered fold: acc[0..8] += row, acc[9..11] running mean with count = index+1
+F3DS_HD void a_fold_row(float acc[12], const float row[12], unsigned index_plus_1) {
+    for (int k = 0; k < 9; ++k) acc[k] += row[k];
+    float count = (float)index_plus_1;
+    float inv = 1 / count;
+    for (int k = 9; k < 12; ++k) acc[k] = acc[k] + inv * (row[k] - acc[k]);
+}
+// region record (16 floats: centroid, normal, mean rgb, Lab) of a merged region from its sums
+F3DS_HD void a_region_from_acc(const float acc[12], unsigned count, float rec[16]) {
+    float c = (float)count;
+    rec[0] = acc[6] / c; rec[1] = acc[7] / c; rec[2] = acc[8] / c;
+    float n4[4];
+    n_plane_normal(acc, count, rec, n4);
+    rec[3] = n4[0]; rec[4] = n4[1]; rec[5] = n4[2];
+    rec[6] = acc[9]; rec[7] = acc[10]; rec[8] = acc[11];
+    n_rgb2lab(rec + 6, rec + 9);
+    rec[12] = rec[13] = rec[14] = rec[15] = 0.0f;
+}
+
+struct MergeParams {
+    int color_metric, geom_metric, merging;
+    float lambda;
+    int bins;
+    const float* cdf_c;       // bins entries (EQUALIZATION)
+    const float* cdf_g;
+};
+// t_c / t_g (src/clustering.cpp:324-376); *err set when the reference's map::at would throw
+F3DS_HD float a_tc(const MergeParams& p, float dc, int* err) {
+    if (p.merging != 2) return p.lambda * dc;
+    short bin = (short)__builtin_floorf(dc * (float)(short)p.bins);
+    if (bin == (short)p.bins) bin--;
+    if (bin < 0 || bin >= (short)p.bins) { *err = -9; return 0.0f; }
+    return p.cdf_c[bin] / 2;
+}
+F3DS_HD float a_tg(const MergeParams& p, float dg, int* err) {
+    if (p.merging != 2) return (1 - p.lambda) * dg;
+    short bin = (short)__builtin_floorf(dg * (float)(short)p.bins);
+    if (bin < 0 || bin >= (short)p.bins) { *err = -9; return 0.0f; }
+    return p.cdf_g[bin] / 2;
+}
+F3DS_HD float a_edge_weight(const MergeParams& p, const float* rec_first, const float* rec_second, int* err) {
+    float dc, dg;
+    n_delta_c_g(rec_first, rec_second, p.color_metric, p.geom_metric, &dc, &dg);
+    return a_tc(p, dc, err) + a_tg(p, dg, err);
+}
+
+// weight-change history of the edges: event h = (epoch, key, previous event of the same edge)
+struct EdgeHist {
+    const uint32_t* ev_epoch;
+    const uint32_t* ev_key;
+    const int* ev_prev;
+};
+// true when edge e precedes edge f in the reference's weight_map (e != f)
+F3DS_HD bool a_edge_before(const EdgeHist& H, uint32_t e, uint32_t ke, int he, uint32_t f, uint32_t kf, int hf) {
+    if (ke != kf) return ke < kf;
+    for (;;) {
+        uint32_t te = H.ev_epoch[he], tf = H.ev_epoch[hf];
+        uint32_t tau = te > tf ? te : tf;
+        if (tau == 0u) return e < f;       // initial insertion order = sorted (a,b) order
+        if (te == tau) he = H.ev_prev[he];
+        if (tf == tau) hf = H.ev_prev[hf];
+        ke = H.ev_key[he]; kf = H.ev_key[hf];
+        if (ke != kf) return ke < kf;
+    }
+}
+
+}  // namespace f3ds
+#endif  // F3DS_ALGO_H_

@@ -1,0 +1,182 @@
+/* f3ds.h -- C-ABI of libf3ds: MI355X-native supervoxel + hierarchical-merge segmenter.
+ *
+ * One call replaces, for one XYZRGBA frame, the whole hot path of the reference
+ * (citations are into /root/reference):
+ *
+ *   frame prelude  (z<0 -> |z|)                         src/supervoxel_clustering.cpp:313-340
+ *   pcl::SupervoxelClustering<PointXYZRGBA> sequence    src/supervoxel_clustering.cpp:348-367
+ *   Clustering::set_initialstate / cluster(threshold)   src/clustering.cpp:605-612, 670-679
+ *   Clustering::get_labeled_cloud / get_colored_cloud   src/clustering.cpp:631-663
+ *
+ * The reference has no FFI of its own (it is a C++ CLI); a maintainer who wants to keep
+ * main() and swap the path would bind exactly these entry points (INTEGRATION.md shows the
+ * replacement block for main()).  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Threading: one f3ds_ctx per host thread / stream; calls on one ctx are serial.
+ * Errors: negative int codes (f3ds_strerror); nothing throws across this boundary.
+ * Memory: caller owns every in/out buffer; the ctx owns its device scratch (grow-only).
+ */
+#ifndef F3DS_H_
+#define F3DS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F3DS_VERSION 100
+
+/* label written for points that belong to no region (non-finite input point, or a voxel no
+ * supervoxel ever claimed).  The reference never emits such points at all
+ * (Clustering::get_labeled_cloud only walks owned voxels, src/clustering.cpp:640-663). */
+#define F3DS_NO_LABEL 0xFFFFFFFFu
+
+/* error codes */
+#define F3DS_OK 0
+#define F3DS_ERR_ARG (-1)          /* null pointer / bad parameter value                        */
+#define F3DS_ERR_NO_DEVICE (-2)    /* HIP runtime found no usable GPU                           */
+#define F3DS_ERR_HIP (-3)          /* a HIP call failed (f3ds_last_hip_error has the text)      */
+#define F3DS_ERR_DEPTH (-4)        /* voxel grid needs more than 21 octree levels               */
+#define F3DS_ERR_LOGIC (-5)        /* call order (e.g. recluster before segment):
+                                      std::logic_error in src/clustering.cpp:671-673            */
+#define F3DS_ERR_RANGE (-6)        /* lambda outside [0,1] / bins < 0:
+                                      std::invalid_argument in src/clustering.cpp:578,593       */
+#define F3DS_ERR_UNSUPPORTED (-7)  /* degenerate input the device path refuses (documented)     */
+#define F3DS_ERR_IO (-8)           /* PCD file could not be read / written                      */
+#define F3DS_ERR_EQ_BIN (-9)       /* --EQ with delta_g == 1.0: map::at throws in the reference
+                                      (src/clustering.cpp:371-372, t_g has no clamp)            */
+#define F3DS_ERR_CAPACITY (-10)    /* output buffer too small                                   */
+
+/* enums mirror include/supervoxel_clustering/clustering.h:58-68 */
+enum { F3DS_LAB_CIEDE00 = 0, F3DS_RGB_EUCL = 1 };
+enum { F3DS_NORMALS_DIFF = 0, F3DS_CONVEX_NORMALS_DIFF = 1 };
+enum { F3DS_MANUAL_LAMBDA = 0, F3DS_ADAPTIVE_LAMBDA = 1, F3DS_EQUALIZATION = 2 };
+
+/* CLI flags of the reference (src/supervoxel_clustering.cpp:187-298) as a plain struct */
+typedef struct f3ds_params {
+    float voxel_res;          /* -v   default 0.008                                      */
+    float seed_res;           /* -s   default 0.08                                       */
+    float w_color;            /* -c   default 0.2                                        */
+    float w_spatial;          /* -z   default 0.4                                        */
+    float w_normal;           /* -n   default 1.0                                        */
+    int32_t use_transform;    /* !--NT  (setUseSingleCameraTransform, :349)              */
+    int32_t color_metric;     /* --RGB -> F3DS_RGB_EUCL, else F3DS_LAB_CIEDE00           */
+    int32_t geom_metric;      /* --CVX -> F3DS_CONVEX_NORMALS_DIFF                       */
+    int32_t merging;          /* --ML / --AL / --EQ                                      */
+    float lambda;             /* --ML value; used only under F3DS_MANUAL_LAMBDA          */
+    int32_t bins;             /* --EQ value; used only under F3DS_EQUALIZATION           */
+    float threshold;          /* -t                                                      */
+    int32_t leaf_order;       /* 0: octree leaves ascending (PCL >= 1.9), 1: descending  */
+    int32_t fold_negative_z;  /* main()'s z<0 -> |z| (:317-321); the CLI always sets 1   */
+} f3ds_params;
+
+typedef struct f3ds_result {
+    uint64_t n_points;            /* N                                                   */
+    uint64_t n_finite;            /* points with finite x,y,z                            */
+    uint32_t n_voxels;            /* V  occupied voxels                                  */
+    uint32_t octree_depth;        /* levels of the voxel grid cube                       */
+    uint32_t n_seed_cells;        /* occupied seed-resolution cells before filtering     */
+    uint32_t n_seeds;             /* seeds kept = supervoxel helpers created             */
+    uint32_t n_supervoxels;       /* S  non-empty supervoxels after the sweeps           */
+    uint32_t n_edges;             /* E  undirected supervoxel adjacencies                */
+    uint32_t n_merges;            /* merges performed below the threshold                */
+    uint32_t n_regions;           /* K  regions left                                     */
+    uint32_t sweeps;              /* max_depth-1 label-propagation sweeps                */
+    float lambda;                 /* lambda actually used (Clustering::get_lambda)       */
+    float ms_total;               /* wall time of the call, host clock                   */
+    float ms_stage[8];            /* device time per stage (HIP events): 0 voxelise,
+                                     1 neighbours+normals, 2 seeds, 3 sweeps, 4 supervoxel
+                                     summaries+edges, 5 merge, 6 labels, 7 reserved      */
+} f3ds_result;
+
+typedef struct f3ds_ctx f3ds_ctx;
+
+void f3ds_default_params(f3ds_params* p);
+int f3ds_version(void);
+const char* f3ds_strerror(int code);
+const char* f3ds_last_hip_error(void);
+
+/* number of visible GPUs (0 when there is none); never initialises a device */
+int f3ds_device_count(void);
+
+/* create a context on `device` with its own stream.  Fails with F3DS_ERR_NO_DEVICE when the
+ * HIP runtime has no GPU: there is no CPU fallback in this library. */
+int f3ds_create(int device, f3ds_ctx** out);
+void f3ds_destroy(f3ds_ctx* ctx);
+
+/* run on a caller-provided hipStream_t (e.g. a torch stream) instead of the ctx's own */
+int f3ds_set_stream(f3ds_ctx* ctx, void* hip_stream);
+
+/* Segment one frame.  `points` is N records {float x,y,z; uint32 rgba} (16 B, rgba packed
+ * a<<24|r<<16|g<<8|b as PCL does).  points_on_device / labels_on_device say where the caller's
+ * buffers live.  point_labels receives N region ids (0..K-1 in the order of
+ * Clustering::get_labeled_cloud, F3DS_NO_LABEL for points outside every region).
+ * Synchronous: returns after the labels are in the caller's buffer. */
+int f3ds_segment(f3ds_ctx* ctx, const void* points, size_t n, int points_on_device,
+                 const f3ds_params* params, uint32_t* point_labels, int labels_on_device,
+                 f3ds_result* result);
+
+/* Clustering::cluster(threshold) again on the supervoxels of the last f3ds_segment call, with
+ * possibly different metric / merging settings (src/clustering.cpp:670-679).  Only the merge
+ * fields of `params` are read. */
+int f3ds_recluster(f3ds_ctx* ctx, const f3ds_params* params, uint32_t* point_labels,
+                   int labels_on_device, f3ds_result* result);
+
+/* Clustering::get_labeled_cloud / get_colored_cloud of the last call: one record per owned
+ * voxel, regions in ascending label order, voxels in leaf order inside each supervoxel,
+ * supervoxels in merge-concatenation order (src/clustering.cpp:640-663, 793-812).
+ * Any of xyz / label / rgba may be NULL.  rgba = Glasbey[label % 256]. */
+int f3ds_get_voxel_cloud(f3ds_ctx* ctx, float* xyz, uint32_t* label, uint32_t* rgba, size_t cap,
+                         size_t* n_out);
+
+/* parity hooks: copy an intermediate array of the last call to host memory */
+enum {
+    F3DS_DBG_GRID = 0,            /* 5 x f64: min_x, min_y, min_z, resolution, depth            */
+    F3DS_DBG_VOXEL_KEYS = 1,      /* V x 3 u32, leaf order                                      */
+    F3DS_DBG_VOXEL_COUNT = 2,     /* V u32 points per voxel                                     */
+    F3DS_DBG_VOXEL_XYZ = 3,       /* V x 3 f32 centroid                                         */
+    F3DS_DBG_VOXEL_RGB = 4,       /* V x 3 f32 mean colour                                      */
+    F3DS_DBG_VOXEL_NORMAL = 5,    /* V x 4 f32 (w = 0)                                          */
+    F3DS_DBG_VOXEL_NEIGHBORS = 6, /* V x 27 i32, slot = (dx+1)*9+(dy+1)*3+(dz+1), -1 = none     */
+    F3DS_DBG_POINT_VOXEL = 7,     /* N i32 voxel of each input point, -1 = non-finite           */
+    F3DS_DBG_SEED_ORIG = 8,       /* n_seed_cells i32: nearest voxel per occupied seed cell     */
+    F3DS_DBG_SEED_KEPT = 9,       /* n_seeds i32: voxels that became helpers (label = index+1)  */
+    F3DS_DBG_VOXEL_SVLABEL = 10,  /* V u32 supervoxel label after the sweeps, 0 = none          */
+    F3DS_DBG_VOXEL_DIST = 11,     /* V f32 VoxelData::distance_ after the sweeps                */
+    F3DS_DBG_SV_LABELS = 12,      /* S u32 labels of non-empty supervoxels, ascending           */
+    F3DS_DBG_SV_CENTROID = 13,    /* S x 10 f32: xyz, rgb, normal4 of each (same order)         */
+    F3DS_DBG_EDGES = 14,          /* E x 2 u32 (a<b), sorted                                    */
+    F3DS_DBG_EDGE_DELTAS = 15,    /* E x 2 f32 (delta_c, delta_g)                               */
+    F3DS_DBG_EDGE_WEIGHTS = 16,   /* E f32 initial weights                                      */
+    F3DS_DBG_MERGES = 17,         /* n_merges x 3 u32: a, b, weight bits                        */
+    F3DS_DBG_VOXEL_REGION = 18,   /* V u32 final region id per voxel (F3DS_NO_LABEL = none)     */
+    F3DS_DBG_SV_REGION = 19       /* S u32 surviving label each supervoxel ended in             */
+};
+int f3ds_get_debug(f3ds_ctx* ctx, int what, void* dst, size_t cap_bytes, size_t* bytes_out);
+
+/* ---- host-side helpers either side of the path (no GPU needed) -------------------------- */
+
+/* PCD v0.7 reader (ascii / binary / binary_compressed), replaces pcl::io::loadPCDFile at
+ * src/supervoxel_clustering.cpp:313.  Fields x y z + rgb|rgba (+ optional label).  Call with
+ * points == NULL to get the point count.  labels may be NULL; missing label field -> 0. */
+int f3ds_pcd_read(const char* path, void* points16, uint32_t* labels, size_t cap, size_t* n_out,
+                  uint32_t* width, uint32_t* height);
+/* PCD writer: fields "x y z rgba" (+ "label" when labels != NULL); mode 0 ascii, 1 binary */
+int f3ds_pcd_write(const char* path, const float* xyz, const uint32_t* rgba,
+                   const uint32_t* labels, size_t n, int mode);
+
+/* deterministic synthetic frames (SplitMix64): kind 0 = pinhole RGB-D room (width x height
+ * pixels), kind 1 = fused multi-view room scene with width*height
+ * samples (config 4).  nan_permille = invalid-depth pixels per thousand. */
+int f3ds_synth_frame(int kind, uint64_t seed, uint32_t width, uint32_t height,
+                     uint32_t nan_permille, void* points16);
+
+/* Glasbey-style lookup used for the coloured cloud (256 entries, r<<16|g<<8|b) */
+uint32_t f3ds_label_color(uint32_t label);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F3DS_H_ */

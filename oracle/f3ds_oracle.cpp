@@ -1,0 +1,1069 @@
+// f3ds_oracle.cpp -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+// nothing under fast-3d-pointcloud-segmentation_amd/ links, imports or calls it.
+//
+// What it restates (citations into /root/reference unless marked [PCL-recall]):
+//   * frame prelude of main()                      src/supervoxel_clustering.cpp:313-340
+//   * pcl::SupervoxelClustering<PointXYZRGBA>      called at src/supervoxel_clustering.cpp:348-367.
+//     PCL (>=1.8, pin 1.10.0), Eigen 3.3.7 and FLANN 1.9.1 are NOT vendored in the reference
+//     and are absent from this image; their algorithms are restated from SURVEY.md section 3.2 /
+//     Appendix A ([PCL-recall]).  PARITY UNPINNED for that half: the reference holds no golden
+//     vector for voxel order, seeds, normals or supervoxel labels.
+//   * Clustering (set_initialstate, init_weights, cluster, merge, get_labeled_cloud)
+//                                                  src/clustering.cpp:53-162,193-251,260-376,384-528,605-663
+//   * ClusteringState / WeightMapT ordering        include/supervoxel_clustering/clustering_state.h:47-123
+//   * ColorUtilities (mean_color, rgb2lab, lab_ciede00, rgb_eucl)
+//                                                  src/color_utilities.cpp:117-160,190-319
+//     rgb2lab calls cv::cvtColor(COLOR_RGB2Lab) (OpenCV 4, absent): restated analytically, PARITY
+//     UNPINNED; lab_ciede00 and rgb_eucl are pinned by the reference's own known-answer tables
+//     (src/color_utilities.cpp:324-349,354-460 -> tests/golden/ciede2000_kat.json).
+//
+// Style: literal.  std::set / std::map / std::list follow the containers the reference and PCL
+// use so that iteration order, tie order and float summation order are the reference's.
+// libm calls on the path go through csrc/f3ds_math.h (IEEE basic operations only) so that the
+// device code can reproduce them bit for bit; build with -DF3DS_ORACLE_LIBM to use libm instead
+// and measure how far that moves the result (tests/test_oracle.py does).
+//
+// Documented fences (places where the reference's behaviour is undefined or unrecoverable):
+//   F1  NaN edge weights break std::multimap's ordering precondition (UB in the reference);
+//       here NaN orders after every number, ties in insertion order.
+//   F2  FLANN's exact 1-NN tie order is traversal dependent; here the lowest voxel index wins.
+//   F3  octree depth > 21 is refused (PCL allows 32).
+//   F4  pcl::GlasbeyLUT's 256 colours are not recoverable offline; f3ds ships its own table.
+
+#include <algorithm>
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/f3ds.h"
+#include "../fast-3d-pointcloud-segmentation_amd/csrc/f3ds_math.h"
+
+namespace {
+
+// ---- libm seam ------------------------------------------------------------------------------
+#ifdef F3DS_ORACLE_LIBM
+inline float o_logf(float x) { return std::log(x); }
+inline float o_atan2f(float y, float x) { return std::atan2(y, x); }
+inline float o_cosf(float x) { return std::cos(x); }
+inline float o_sinf(float x) { return std::sin(x); }
+inline double o_atan2(double y, double x) { return std::atan2(y, x); }
+inline double o_cos(double x) { return std::cos(x); }
+inline double o_sin(double x) { return std::sin(x); }
+inline double o_exp(double x) { return std::exp(x); }
+inline double o_pow7(double x) { return std::pow(x, 7.0); }
+inline double o_sq(double x) { return std::pow(x, 2.0); }
+inline float o_gamma(float c) { return (float)std::pow((double)((c + 0.055f) / 1.055f), 2.4); }
+inline float o_cbrtf(float x) { return std::cbrt(x); }
+inline double o_log(double x) { return std::log(x); }
+#else
+inline float o_logf(float x) { return f3ds::m_logf(x); }
+inline float o_atan2f(float y, float x) { return f3ds::m_atan2f(y, x); }
+inline float o_cosf(float x) { return f3ds::m_cosf(x); }
+inline float o_sinf(float x) { return f3ds::m_sinf(x); }
+inline double o_atan2(double y, double x) { return f3ds::m_atan2(y, x); }
+inline double o_cos(double x) { return f3ds::m_cos(x); }
+inline double o_sin(double x) { return f3ds::m_sin(x); }
+inline double o_exp(double x) { return f3ds::m_exp(x); }
+inline double o_pow7(double x) { double x2 = x * x; double x4 = x2 * x2; return (x4 * x2) * x; }
+inline double o_sq(double x) { return x * x; }
+inline float o_gamma(float c) { return (float)f3ds::m_pow_pos((double)((c + 0.055f) / 1.055f), 2.4); }
+inline float o_cbrtf(float x) { return (float)f3ds::m_cbrt_pos((double)x); }
+inline double o_log(double x) { return f3ds::m_log(x); }
+#endif
+
+struct P16 { float x, y, z; uint32_t rgba; };
+
+inline bool finite3(float x, float y, float z) { return std::isfinite(x) && std::isfinite(y) && std::isfinite(z); }
+
+// ---- Eigen reduction orders [PCL-recall: Eigen 3.3 Redux.h] -----------------------------------
+// 3-vectors are not vectorised: redux_novec_unroller splits [0,3) into [0,1) + [1,3).
+inline float sum3(float a, float b, float c) { return a + (b + c); }
+inline float dot3(const float* a, const float* b) { return sum3(a[0] * b[0], a[1] * b[1], a[2] * b[2]); }
+inline float norm3(const float* a) { return std::sqrt(dot3(a, a)); }
+// 4-vectors use one SSE packet; predux with SSE3 hadd gives (a0+a1)+(a2+a3).
+inline float sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
+inline float dot4(const float* a, const float* b) { return sum4(a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]); }
+inline void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// Eigen 3.3 normalize(): z = squaredNorm(); if (z > 0) v /= sqrt(z)
+inline void normalize4(float* v) {
+    float z = dot4(v, v);
+    if (z > 0.0f) { float s = std::sqrt(z); v[0] /= s; v[1] /= s; v[2] /= s; v[3] /= s; }
+}
+
+// ---- pcl::computeRoots2 / computeRoots / eigen33 [PCL-recall, SURVEY.md A5] -------------------
+void compute_roots2(float b, float c, float* roots) {
+    roots[0] = 0.0f;
+    float d = (float)((double)(b * b) - 4.0 * (double)c);
+    if (d < 0.0f) d = 0.0f;
+    float sd = std::sqrt(d);
+    roots[2] = 0.5f * (b + sd);
+    roots[1] = 0.5f * (b - sd);
+}
+void compute_roots(const float m[3][3], float* roots) {
+    float c0 = m[0][0] * m[1][1] * m[2][2] + 2.0f * m[0][1] * m[0][2] * m[1][2] - m[0][0] * m[1][2] * m[1][2] -
+               m[1][1] * m[0][2] * m[0][2] - m[2][2] * m[0][1] * m[0][1];
+    float c1 = m[0][0] * m[1][1] - m[0][1] * m[0][1] + m[0][0] * m[2][2] - m[0][2] * m[0][2] + m[1][1] * m[2][2] -
+               m[1][2] * m[1][2];
+    float c2 = m[0][0] + m[1][1] + m[2][2];
+    if (std::fabs(c0) < FLT_EPSILON) {
+        compute_roots2(c2, c1, roots);
+    } else {
+        const float s_inv3 = (float)(1.0 / 3.0);
+        const float s_sqrt3 = std::sqrt(3.0f);
+        float c2_over_3 = c2 * s_inv3;
+        float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+        if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+        float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+        float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+        if (q > 0.0f) q = 0.0f;
+        float rho = std::sqrt(-a_over_3);
+        float theta = o_atan2f(std::sqrt(-q), half_b) * s_inv3;
+        float cos_theta = o_cosf(theta);
+        float sin_theta = o_sinf(theta);
+        roots[0] = c2_over_3 + 2.0f * rho * cos_theta;
+        roots[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+        roots[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+        if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+        if (roots[1] >= roots[2]) {
+            std::swap(roots[1], roots[2]);
+            if (roots[0] >= roots[1]) std::swap(roots[0], roots[1]);
+        }
+        if (roots[0] <= 0.0f) compute_roots2(c2, c1, roots);
+    }
+}
+// smallest eigenvalue + its eigenvector of a symmetric 3x3
+void eigen33(const float cov[3][3], float* eigenvalue, float* evec) {
+    float scale = std::fabs(cov[0][0]);              // cwiseAbs().maxCoeff(): Eigen's visitor starts at (0,0)
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) { float v = std::fabs(cov[i][j]); if (v > scale) scale = v; }
+    if (scale <= FLT_MIN) scale = 1.0f;
+    float m[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i][j] = cov[i][j] / scale;
+    float roots[3];
+    compute_roots(m, roots);
+    *eigenvalue = roots[0] * scale;
+    m[0][0] -= roots[0]; m[1][1] -= roots[0]; m[2][2] -= roots[0];
+    float v1[3], v2[3], v3[3];
+    cross3(m[0], m[1], v1);
+    cross3(m[0], m[2], v2);
+    cross3(m[1], m[2], v3);
+    float l1 = dot3(v1, v1), l2 = dot3(v2, v2), l3 = dot3(v3, v3);
+    const float* v; float l;
+    if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
+    else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
+    else { v = v3; l = l3; }
+    float s = std::sqrt(l);
+    evec[0] = v[0] / s; evec[1] = v[1] / s; evec[2] = v[2] / s;
+}
+
+// pcl::computePointNormal on a sequence of points given in order (is_dense path) followed by
+// flipNormalTowardsViewpoint(point, 0,0,0), normal[3]=0, normalize()  [PCL-recall A5]
+struct XYZ { float x, y, z; };
+template <class It, class Get>
+void point_normal(It begin, It end, size_t count, Get get, const float vp_point[3], float normal[4], float* curvature) {
+    if (count < 3) {
+        normal[0] = normal[1] = normal[2] = normal[3] = std::numeric_limits<float>::quiet_NaN();
+        *curvature = normal[0];
+    } else {
+        float accu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (It it = begin; it != end; ++it) {
+            XYZ p = get(*it);
+            accu[0] += p.x * p.x; accu[1] += p.x * p.y; accu[2] += p.x * p.z;
+            accu[3] += p.y * p.y; accu[4] += p.y * p.z; accu[5] += p.z * p.z;
+            accu[6] += p.x; accu[7] += p.y; accu[8] += p.z;
+        }
+        float cnt = (float)count;
+        for (int i = 0; i < 9; ++i) accu[i] /= cnt;
+        float cov[3][3];
+        cov[0][0] = accu[0] - accu[6] * accu[6];
+        cov[0][1] = accu[1] - accu[6] * accu[7];
+        cov[0][2] = accu[2] - accu[6] * accu[8];
+        cov[1][1] = accu[3] - accu[7] * accu[7];
+        cov[1][2] = accu[4] - accu[7] * accu[8];
+        cov[2][2] = accu[5] - accu[8] * accu[8];
+        cov[1][0] = cov[0][1]; cov[2][0] = cov[0][2]; cov[2][1] = cov[1][2];
+        float ev, vec[3];
+        eigen33(cov, &ev, vec);
+        normal[0] = vec[0]; normal[1] = vec[1]; normal[2] = vec[2];
+        float eig_sum = cov[0][0] + cov[1][1] + cov[2][2];
+        *curvature = (eig_sum != 0.0f) ? std::fabs(ev / eig_sum) : 0.0f;
+        float cen[4] = {accu[6], accu[7], accu[8], 1.0f};
+        normal[3] = 0.0f;
+        normal[3] = -1.0f * dot4(normal, cen);
+    }
+    // flipNormalTowardsViewpoint
+    float vp[4] = {0.0f - vp_point[0], 0.0f - vp_point[1], 0.0f - vp_point[2], 0.0f};
+    float cos_theta = dot4(vp, normal);
+    if (cos_theta < 0.0f) {
+        normal[0] *= -1.0f; normal[1] *= -1.0f; normal[2] *= -1.0f; normal[3] *= -1.0f;
+        // (Hessian component recomputed in PCL; the caller overwrites it with 0 next)
+    }
+    normal[3] = 0.0f;
+    normalize4(normal);
+}
+
+// ---- colour [src/color_utilities.cpp] ----------------------------------------------------------
+const float RGB_RANGE = 441.672943f;   // include/supervoxel_clustering/color_utilities.h:62
+const float LAB_RANGE = 137.3607f;     // include/supervoxel_clustering/color_utilities.h:63
+
+// cv::cvtColor(COLOR_RGB2Lab) on CV_32FC3, restated analytically -- unpinned
+void rgb2lab(const float rgb[3], float lab[3]) {
+    float c[3];
+    for (int i = 0; i < 3; ++i) {
+        float v = rgb[i] / 255;                       // src/color_utilities.cpp:153-155
+        v = v <= 0.04045f ? v / 12.92f : o_gamma(v);
+        c[i] = v;
+    }
+    float X = (c[0] * 0.412453f + c[1] * 0.357580f + c[2] * 0.180423f) / 0.950456f;
+    float Y = (c[0] * 0.212671f + c[1] * 0.715160f + c[2] * 0.072169f);
+    float Z = (c[0] * 0.019334f + c[1] * 0.119193f + c[2] * 0.950227f) / 1.088754f;
+    float fx = X > 0.008856f ? o_cbrtf(X) : 7.787f * X + 16.0f / 116.0f;
+    float fy = Y > 0.008856f ? o_cbrtf(Y) : 7.787f * Y + 16.0f / 116.0f;
+    float fz = Z > 0.008856f ? o_cbrtf(Z) : 7.787f * Z + 16.0f / 116.0f;
+    lab[0] = Y > 0.008856f ? 116.0f * fy - 16.0f : 903.3f * Y;
+    lab[1] = 500.0f * (fx - fy);
+    lab[2] = 200.0f * (fy - fz);
+}
+
+// src/color_utilities.cpp:190-294, kL = kC = kH = 1
+float lab_ciede00(const float lab1[3], const float lab2[3]) {
+    const double kL = 1.0, kC = 1.0, kH = 1.0;
+    float L1 = lab1[0], a1 = lab1[1], b1 = lab1[2];
+    float L2 = lab2[0], a2 = lab2[1], b2 = lab2[2];
+    double Cab1 = std::sqrt(a1 * a1 + b1 * b1);      // float sqrt, widened
+    double Cab2 = std::sqrt(a2 * a2 + b2 * b2);
+    double Cab = (Cab1 + Cab2) / 2.0;
+    double G = 0.5 * (1.0 - std::sqrt(o_pow7(Cab) / (o_pow7(Cab) + 6103515625.0)));
+    double ap1 = (1.0 + G) * a1;
+    double ap2 = (1.0 + G) * a2;
+    double Cp1 = std::sqrt(ap1 * ap1 + b1 * b1);
+    double Cp2 = std::sqrt(ap2 * ap2 + b2 * b2);
+    double Cp_prod = (Cp2 * Cp1);
+    const double PI = 3.14159265358979323846;
+    double hp1 = 0;
+    if ((std::abs(ap1) + std::abs(b1)) != 0.0) {
+        hp1 = o_atan2(b1, ap1);
+        if (hp1 < 0) hp1 += 2.0 * PI;
+    }
+    double hp2 = 0;
+    if ((std::abs(ap2) + std::abs(b2)) != 0.0) {
+        hp2 = o_atan2(b2, ap2);
+        if (hp2 < 0) hp2 += 2.0 * PI;
+    }
+    double dL = (L2 - L1);
+    double dC = (Cp2 - Cp1);
+    double dhp = (hp2 - hp1);
+    if (dhp > PI) dhp -= 2.0 * PI;
+    else if (dhp < -PI) dhp += 2.0 * PI;
+    if (Cp_prod == 0.0) dhp = 0.0;
+    double dH = 2.0 * std::sqrt(Cp_prod) * o_sin(dhp / 2.0);
+    double Lp = (L2 + L1) / 2.0;
+    double Cp = (Cp1 + Cp2) / 2.0;
+    double hp = (hp1 + hp2) / 2.0;
+    if (std::abs(hp1 - hp2) > PI) hp -= PI;
+    if (hp < 0) hp += 2.0 * PI;
+    if (Cp_prod == 0.0) hp = hp1 + hp2;
+    double Lpm502 = (Lp - 50.0) * (Lp - 50.0);
+    double T = 1.0 - 0.17 * o_cos(hp - PI / 6.0) + 0.24 * o_cos(2.0 * hp) + 0.32 * o_cos(3.0 * hp + PI / 30.0) -
+               0.20 * o_cos(4.0 * hp - 63.0 * PI / 180.0);
+    double dheta_rad = (30.0 * PI / 180.0) * o_exp(-o_sq(((180.0 / PI * hp - 275.0) / 25.0)));
+    double Rc = 2.0 * std::sqrt(o_pow7(Cp) / (o_pow7(Cp) + 6103515625.0));
+    double kLSL = kL * (1.0 + 0.015 * Lpm502 / std::sqrt(20.0 + Lpm502));
+    double kLSC = kC * (1.0 + 0.045 * Cp);
+    double kHSH = kH * (1.0 + 0.015 * Cp * T);
+    double RT = -o_sin(2.0 * dheta_rad) * Rc;
+    float delta_e = (float)std::sqrt(o_sq((dL / kLSL)) + o_sq((dC / kLSC)) + o_sq((dH / kHSH)) +
+                                     RT * (dC / kLSC) * (dH / kHSH));
+    return delta_e;
+}
+
+// src/color_utilities.cpp:304-319
+float rgb_eucl(const float rgb1[3], const float rgb2[3]) {
+    float rd = (float)((double)(rgb1[0] - rgb2[0]) * (double)(rgb1[0] - rgb2[0]));   // std::pow(float,int) -> double
+    float gd = (float)((double)(rgb1[1] - rgb2[1]) * (double)(rgb1[1] - rgb2[1]));
+    float bd = (float)((double)(rgb1[2] - rgb2[2]) * (double)(rgb1[2] - rgb2[2]));
+    return std::sqrt(rd + gd + bd);
+}
+
+// ---- VCCS state [PCL-recall] -------------------------------------------------------------------
+struct Helper;
+struct Voxel {
+    uint32_t key[3];
+    uint32_t num_points = 0;
+    float xyz[3] = {0, 0, 0};
+    float rgb[3] = {0, 0, 0};
+    float normal[4] = {0, 0, 0, 0};
+    float curvature = 0;
+    int idx = -1;
+    Helper* owner = nullptr;
+    float distance = FLT_MAX;
+    uint32_t svlabel = 0;         // owner label kept after the helper list is gone
+    std::vector<int> nbrs;        // leaf ordinals, std::list order of computeNeighbors
+    int nbr_slot[27];
+    uint32_t rgba_trunc() const {   // VoxelData::getPoint
+        return (uint32_t)rgb[0] << 16 | (uint32_t)rgb[1] << 8 | (uint32_t)rgb[2];
+    }
+};
+struct Centroid {
+    float xyz[3] = {0, 0, 0};
+    float rgb[3] = {0, 0, 0};
+    float normal[4] = {0, 0, 0, 0};
+};
+struct Helper {
+    uint32_t label;
+    std::set<int> leaves;   // ordered by idx_ (compareLeaves)
+    Centroid c;
+};
+struct SvPoint { float x, y, z; uint8_t r, g, b; };
+struct Supervoxel {
+    float centroid[3];
+    float normal[3];
+    std::vector<SvPoint> voxels;
+    std::vector<int> voxel_idx;   // leaf ordinals, parallel to voxels (for the label output)
+    float mean_rgb[3];
+    bool mean_valid = false;
+    std::vector<uint32_t> leaves;   // original supervoxel labels in concatenation order
+};
+typedef std::shared_ptr<Supervoxel> SvPtr;
+
+struct NanLast {   // fence F1
+    bool operator()(float a, float b) const {
+        if (a != a) return false;
+        if (b != b) return true;
+        return a < b;
+    }
+};
+typedef std::multimap<float, std::pair<uint32_t, uint32_t>, NanLast> WeightMap;
+
+inline uint64_t morton(uint32_t x, uint32_t y, uint32_t z, int depth) {
+    uint64_t code = 0;
+    for (int b = depth - 1; b >= 0; --b)
+        code = (code << 3) | (uint64_t)((((x >> b) & 1u) << 2) | (((y >> b) & 1u) << 1) | ((z >> b) & 1u));
+    return code;
+}
+inline uint64_t pack_key(uint32_t x, uint32_t y, uint32_t z) { return ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z; }
+
+// OctreePointCloud::getKeyBitSize for an empty tree [PCL-recall A2]
+struct Cube { double min[3], max[3]; double res; int depth; };
+bool key_bit_size(Cube& c) {
+    const float minValue = std::numeric_limits<float>::epsilon();
+    unsigned mk[3];
+    for (int a = 0; a < 3; ++a) mk[a] = (unsigned)std::ceil((c.max[a] - c.min[a] - minValue) / c.res);
+    unsigned max_voxels = std::max(std::max(std::max(mk[0], mk[1]), mk[2]), 2u);
+    unsigned d = std::min(32u, (unsigned)std::ceil(o_log((double)max_voxels) / o_log(2.0) - minValue));
+    if (d > 21) return false;   // fence F3
+    c.depth = (int)d;
+    double side = (double)(1u << d) * c.res;
+    for (int a = 0; a < 3; ++a) {
+        double over = (side - (c.max[a] - c.min[a])) / 2.0;
+        if (over > minValue) { c.min[a] -= over; c.max[a] += over; }
+    }
+    return true;
+}
+
+}  // namespace
+
+struct f3ds_oracle {
+    f3ds_params prm;
+    size_t n = 0;
+    Cube cube;
+    std::vector<Voxel> vox;                  // leaf order
+    std::vector<int> point_voxel;
+    std::vector<int> seed_orig, seed_kept;
+    std::vector<uint32_t> sv_labels;
+    std::vector<float> sv_centroid;          // S x 10
+    std::vector<uint32_t> edges;             // E x 2
+    std::vector<float> edge_deltas;          // E x 2
+    std::vector<float> edge_weights;         // E
+    std::vector<uint32_t> merges;            // M x 3
+    std::vector<uint32_t> voxel_region;      // V
+    std::vector<uint32_t> sv_region;         // S
+    std::map<uint32_t, SvPtr> initial_segments;
+    std::multimap<uint32_t, uint32_t> adjacency;
+    std::map<uint32_t, SvPtr> segments;      // final state
+    f3ds_result res;
+    int error = 0;
+};
+
+namespace {
+
+float voxel_distance(const f3ds_params& p, const Centroid& c, const Voxel& v) {
+    float d[3] = {c.xyz[0] - v.xyz[0], c.xyz[1] - v.xyz[1], c.xyz[2] - v.xyz[2]};
+    float spatial_dist = norm3(d) / p.seed_res;
+    float e[3] = {c.rgb[0] - v.rgb[0], c.rgb[1] - v.rgb[1], c.rgb[2] - v.rgb[2]};
+    float color_dist = norm3(e) / 255.0f;
+    float cos_angle_normal = 1.0f - std::abs(dot4(c.normal, v.normal));
+    return cos_angle_normal * p.w_normal + color_dist * p.w_color + spatial_dist * p.w_spatial;
+}
+
+// ---- stage 1: prepareForSegmentation ---------------------------------------------------------
+int voxelise(f3ds_oracle& o, const std::vector<P16>& pts) {
+    const f3ds_params& prm = o.prm;
+    const size_t n = pts.size();
+    auto transform = [&](float& x, float& y, float& z) {
+        if (prm.use_transform) { x /= z; y /= z; z = o_logf(z); }
+    };
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    size_t n_bbox = 0;
+    o.res.n_finite = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (finite3(pts[i].x, pts[i].y, pts[i].z)) o.res.n_finite++;
+        float x = pts[i].x, y = pts[i].y, z = pts[i].z;
+        transform(x, y, z);
+        if (!finite3(x, y, z)) continue;
+        if (x < mn[0]) mn[0] = x;
+        if (y < mn[1]) mn[1] = y;
+        if (z < mn[2]) mn[2] = z;
+        if (x > mx[0]) mx[0] = x;
+        if (y > mx[1]) mx[1] = y;
+        if (z > mx[2]) mx[2] = z;
+        n_bbox++;
+    }
+    o.point_voxel.assign(n, -1);
+    o.cube.res = (double)prm.voxel_res;
+    if (n_bbox == 0) { o.cube.depth = 0; for (int a = 0; a < 3; ++a) o.cube.min[a] = o.cube.max[a] = 0; return 0; }
+    for (int a = 0; a < 3; ++a) { o.cube.min[a] = std::min((double)mn[a], (double)mx[a]); o.cube.max[a] = std::max((double)mn[a], (double)mx[a]); }
+    if (!key_bit_size(o.cube)) return F3DS_ERR_DEPTH;
+
+    std::unordered_map<uint64_t, int> leaf_of_key;
+    std::vector<Voxel> leaves;
+    std::vector<int> point_leaf(n, -1);
+    for (size_t i = 0; i < n; ++i) {
+        const P16& p = pts[i];
+        if (!finite3(p.x, p.y, p.z)) continue;
+        uint32_t k[3] = {0, 0, 0};
+        float x = p.x, y = p.y, z = p.z;
+        transform(x, y, z);
+        if (!prm.use_transform || finite3(x, y, z)) {
+            k[0] = (unsigned)(((double)x - o.cube.min[0]) / o.cube.res);
+            k[1] = (unsigned)(((double)y - o.cube.min[1]) / o.cube.res);
+            k[2] = (unsigned)(((double)z - o.cube.min[2]) / o.cube.res);
+        }
+        uint64_t pk = pack_key(k[0], k[1], k[2]);
+        auto it = leaf_of_key.find(pk);
+        int li;
+        if (it == leaf_of_key.end()) {
+            li = (int)leaves.size();
+            leaf_of_key.emplace(pk, li);
+            leaves.emplace_back();
+            leaves.back().key[0] = k[0]; leaves.back().key[1] = k[1]; leaves.back().key[2] = k[2];
+        } else li = it->second;
+        Voxel& v = leaves[li];
+        ++v.num_points;
+        v.xyz[0] += p.x; v.xyz[1] += p.y; v.xyz[2] += p.z;
+        v.rgb[0] += (float)((p.rgba >> 16) & 255u);
+        v.rgb[1] += (float)((p.rgba >> 8) & 255u);
+        v.rgb[2] += (float)(p.rgba & 255u);
+        point_leaf[i] = li;
+    }
+    // depth-first leaf order = Morton order of the keys, x most significant [PCL-recall A2]
+    const int V = (int)leaves.size();
+    std::vector<std::pair<uint64_t, int>> order(V);
+    for (int i = 0; i < V; ++i) order[i] = {morton(leaves[i].key[0], leaves[i].key[1], leaves[i].key[2], o.cube.depth), i};
+    std::sort(order.begin(), order.end());
+    if (prm.leaf_order == 1) std::reverse(order.begin(), order.end());
+    std::vector<int> new_idx(V);
+    o.vox.resize(V);
+    for (int r = 0; r < V; ++r) { new_idx[order[r].second] = r; o.vox[r] = leaves[order[r].second]; o.vox[r].idx = r; }
+    for (size_t i = 0; i < n; ++i) if (point_leaf[i] >= 0) o.point_voxel[i] = new_idx[point_leaf[i]];
+    std::unordered_map<uint64_t, int> idx_of_key;
+    idx_of_key.reserve(V * 2);
+    for (int r = 0; r < V; ++r) idx_of_key.emplace(pack_key(o.vox[r].key[0], o.vox[r].key[1], o.vox[r].key[2]), r);
+    const uint32_t max_key = (1u << o.cube.depth) - 1u;
+    for (int r = 0; r < V; ++r) {
+        Voxel& v = o.vox[r];
+        float cnt = (float)v.num_points;                    // computeData
+        for (int a = 0; a < 3; ++a) { v.xyz[a] /= cnt; v.rgb[a] /= cnt; }
+        for (int s = 0; s < 27; ++s) v.nbr_slot[s] = -1;    // computeNeighbors
+        int lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = v.key[a] > 0 ? -1 : 0; hi[a] = v.key[a] == max_key ? 0 : 1; }
+        for (int dx = lo[0]; dx <= hi[0]; ++dx)
+            for (int dy = lo[1]; dy <= hi[1]; ++dy)
+                for (int dz = lo[2]; dz <= hi[2]; ++dz) {
+                    auto it = idx_of_key.find(pack_key(v.key[0] + dx, v.key[1] + dy, v.key[2] + dz));
+                    if (it != idx_of_key.end()) { v.nbrs.push_back(it->second); v.nbr_slot[(dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = it->second; }
+                }
+    }
+    // computeVoxelData: normals from the duplicate-keeping two-ring index list
+    std::vector<int> indices;
+    for (int r = 0; r < V; ++r) {
+        Voxel& v = o.vox[r];
+        indices.clear();
+        indices.push_back(r);
+        for (int nb : v.nbrs) {
+            indices.push_back(nb);
+            for (int nb2 : o.vox[nb].nbrs) indices.push_back(nb2);
+        }
+        point_normal(indices.begin(), indices.end(), indices.size(),
+                     [&](int i) { return XYZ{o.vox[i].xyz[0], o.vox[i].xyz[1], o.vox[i].xyz[2]}; }, v.xyz, v.normal, &v.curvature);
+        v.owner = nullptr;
+        v.distance = FLT_MAX;
+    }
+    return 0;
+}
+
+// ---- stage 2: selectInitialSupervoxelSeeds [PCL-recall A6] -----------------------------------
+int select_seeds(f3ds_oracle& o) {
+    const f3ds_params& prm = o.prm;
+    const int V = (int)o.vox.size();
+    o.seed_orig.clear(); o.seed_kept.clear();
+    if (V == 0) return 0;
+    // OctreePointCloudSearch(seed_res) grown point by point (adoptBoundingBoxToPoint)
+    const float minValue = std::numeric_limits<float>::epsilon();
+    Cube sc; sc.res = (double)prm.seed_res; sc.depth = 0;
+    bool defined = false;
+    std::vector<uint32_t> kx(V), ky(V), kz(V);
+    for (int i = 0; i < V; ++i) {
+        const float* p = o.vox[i].xyz;   // voxel_centroid_cloud_ point (float)
+        if (!finite3(p[0], p[1], p[2])) { kx[i] = ky[i] = kz[i] = 0xFFFFFFFFu; continue; }
+        while (true) {
+            bool lo[3], up[3];
+            for (int a = 0; a < 3; ++a) { lo[a] = (double)p[a] < sc.min[a]; up[a] = (double)p[a] >= sc.max[a]; }
+            if (lo[0] || lo[1] || lo[2] || up[0] || up[1] || up[2] || !defined) {
+                if (defined) {
+                    double side = (double)(1u << sc.depth) * sc.res;
+                    uint32_t off = 1u << sc.depth;
+                    for (int a = 0; a < 3; ++a) {
+                        if (!up[a]) {
+                            sc.min[a] -= side;
+                            std::vector<uint32_t>& k = a == 0 ? kx : (a == 1 ? ky : kz);
+                            for (int j = 0; j < i; ++j) if (k[j] != 0xFFFFFFFFu) k[j] += off;   // old root becomes the upper child
+                        }
+                    }
+                    sc.depth++;
+                    if (sc.depth > 21) return F3DS_ERR_DEPTH;
+                    side = (double)(1u << sc.depth) * sc.res - minValue;
+                    for (int a = 0; a < 3; ++a) sc.max[a] = sc.min[a] + side;
+                } else {
+                    for (int a = 0; a < 3; ++a) { sc.min[a] = (double)p[a] - sc.res / 2; sc.max[a] = (double)p[a] + sc.res / 2; }
+                    if (!key_bit_size(sc)) return F3DS_ERR_DEPTH;
+                    defined = true;
+                }
+            } else break;
+        }
+        kx[i] = (unsigned)(((double)p[0] - sc.min[0]) / sc.res);
+        ky[i] = (unsigned)(((double)p[1] - sc.min[1]) / sc.res);
+        kz[i] = (unsigned)(((double)p[2] - sc.min[2]) / sc.res);
+    }
+    // occupied cells, ascending child order (x<<2|y<<1|z)
+    std::map<uint64_t, std::vector<int>> cells;        // morton -> voxels inside
+    std::unordered_map<uint64_t, std::vector<int>> cell_by_key;
+    for (int i = 0; i < V; ++i) {
+        if (kx[i] == 0xFFFFFFFFu) continue;
+        cells[morton(kx[i], ky[i], kz[i], sc.depth)].push_back(i);
+        cell_by_key[pack_key(kx[i], ky[i], kz[i])].push_back(i);
+    }
+    auto sqdist = [&](const float* a, const float* b) {   // flann::L2_Simple<float>
+        float r = 0.0f;
+        for (int k = 0; k < 3; ++k) { float d = a[k] - b[k]; r += d * d; }
+        return r;
+    };
+    for (auto& kv : cells) {
+        int any = kv.second[0];
+        uint32_t cx = kx[any], cy = ky[any], cz = kz[any];
+        float centre[3];
+        centre[0] = (float)(((double)cx + 0.5f) * sc.res + sc.min[0]);
+        centre[1] = (float)(((double)cy + 0.5f) * sc.res + sc.min[1]);
+        centre[2] = (float)(((double)cz + 0.5f) * sc.res + sc.min[2]);
+        // exact 1-NN; the cell itself is occupied so the answer lies inside the 3x3x3 block
+        int best = -1; float bestd = 0;
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+            int64_t x = (int64_t)cx + dx, y = (int64_t)cy + dy, z = (int64_t)cz + dz;
+            if (x < 0 || y < 0 || z < 0) continue;
+            auto it = cell_by_key.find(pack_key((uint32_t)x, (uint32_t)y, (uint32_t)z));
+            if (it == cell_by_key.end()) continue;
+            for (int j : it->second) {
+                float d = sqdist(centre, o.vox[j].xyz);
+                if (best < 0 || d < bestd || (d == bestd && j < best)) { best = j; bestd = d; }   // fence F2
+            }
+        }
+        o.seed_orig.push_back(best);
+    }
+    float search_radius = 0.5f * prm.seed_res;
+    float min_points = 0.05f * (search_radius) * (search_radius) * 3.1415926536f / (prm.voxel_res * prm.voxel_res);
+    float r2 = (float)((double)search_radius * (double)search_radius);
+    for (size_t i = 0; i < o.seed_orig.size(); ++i) {
+        int s = o.seed_orig[i];
+        int num = 0;
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+            int64_t x = (int64_t)kx[s] + dx, y = (int64_t)ky[s] + dy, z = (int64_t)kz[s] + dz;
+            if (x < 0 || y < 0 || z < 0) continue;
+            auto it = cell_by_key.find(pack_key((uint32_t)x, (uint32_t)y, (uint32_t)z));
+            if (it == cell_by_key.end()) continue;
+            for (int j : it->second) if (sqdist(o.vox[s].xyz, o.vox[j].xyz) < r2) num++;
+        }
+        if (num > min_points) o.seed_kept.push_back(s);
+    }
+    return 0;
+}
+
+// ---- stage 3: createSupervoxelHelpers / expandSupervoxels / makeSupervoxels ------------------
+void expand_supervoxels(f3ds_oracle& o, std::list<Helper>& helpers) {
+    const f3ds_params& prm = o.prm;
+    for (size_t i = 0; i < o.seed_kept.size(); ++i) {
+        helpers.emplace_back();
+        Helper& h = helpers.back();
+        h.label = (uint32_t)(i + 1);
+        Voxel& leaf = o.vox[o.seed_kept[i]];
+        h.leaves.insert(leaf.idx);      // addLeaf
+        leaf.owner = &h;
+    }
+    int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
+    o.res.sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0;
+    for (int it = 1; it < max_depth; ++it) {
+        for (Helper& h : helpers) {     // SupervoxelHelper::expand
+            std::vector<int> new_owned;
+            for (int li : h.leaves) {
+                for (int nb : o.vox[li].nbrs) {
+                    Voxel& nv = o.vox[nb];
+                    if (nv.owner == &h) continue;
+                    float dist = voxel_distance(prm, h.c, nv);
+                    if (dist < nv.distance) {
+                        nv.distance = dist;
+                        if (nv.owner != &h) {
+                            if (nv.owner) nv.owner->leaves.erase(nb);
+                            nv.owner = &h;
+                            new_owned.push_back(nb);
+                        }
+                    }
+                }
+            }
+            for (int nb : new_owned) h.leaves.insert(nb);
+        }
+        for (auto hit = helpers.begin(); hit != helpers.end();) {
+            if (hit->leaves.empty()) hit = helpers.erase(hit);
+            else {                       // updateCentroid
+                Centroid& c = hit->c;
+                for (int a = 0; a < 4; ++a) c.normal[a] = 0;
+                for (int a = 0; a < 3; ++a) { c.xyz[a] = 0; c.rgb[a] = 0; }
+                for (int li : hit->leaves) {
+                    const Voxel& v = o.vox[li];
+                    for (int a = 0; a < 4; ++a) c.normal[a] += v.normal[a];
+                    for (int a = 0; a < 3; ++a) { c.xyz[a] += v.xyz[a]; c.rgb[a] += v.rgb[a]; }
+                }
+                normalize4(c.normal);
+                float sz = (float)hit->leaves.size();
+                for (int a = 0; a < 3; ++a) { c.xyz[a] /= sz; c.rgb[a] /= sz; }
+                ++hit;
+            }
+        }
+    }
+}
+
+// ---- stage 4: Clustering ----------------------------------------------------------------------
+const float* mean_color(Supervoxel& s) {      // src/color_utilities.cpp:117-142 (cached: same value every call)
+    if (!s.mean_valid) {
+        float count = 0, mr = 0, mg = 0, mb = 0;
+        for (const SvPoint& v : s.voxels) {
+            float r = v.r, g = v.g, b = v.b;
+            count++;
+            mr = mr + (1 / count) * (r - mr);
+            mg = mg + (1 / count) * (g - mg);
+            mb = mb + (1 / count) * (b - mb);
+        }
+        s.mean_rgb[0] = mr; s.mean_rgb[1] = mg; s.mean_rgb[2] = mb;
+        s.mean_valid = true;
+    }
+    return s.mean_rgb;
+}
+
+struct Clusterer {
+    f3ds_params prm;
+    float lambda = 0.5f;
+    short bins_num = 500;
+    std::map<short, float> cdf_c, cdf_g;
+    int error = 0;
+
+    // src/clustering.cpp:79-96 and :53-67
+    static void unit_c(const Supervoxel& a, const Supervoxel& b, float C[3]) {
+        C[0] = a.centroid[0] - b.centroid[0]; C[1] = a.centroid[1] - b.centroid[1]; C[2] = a.centroid[2] - b.centroid[2];
+        float n = norm3(C);
+        C[0] /= n; C[1] /= n; C[2] /= n;
+    }
+    static float normals_diff(const Supervoxel& a, const Supervoxel& b) {
+        float C[3]; unit_c(a, b, C);
+        float cr[3]; cross3(a.normal, b.normal, cr);
+        float N1xN2 = norm3(cr);
+        float N1_C = std::abs(dot3(a.normal, C));
+        float N2_C = std::abs(dot3(b.normal, C));
+        return (N1xN2 + N1_C + N2_C) / 3;
+    }
+    static bool is_convex(const Supervoxel& a, const Supervoxel& b) {
+        float C[3]; unit_c(a, b, C);
+        return dot3(a.normal, C) >= dot3(b.normal, C);
+    }
+    // src/clustering.cpp:107-142
+    std::pair<float, float> delta_c_g(Supervoxel& s1, Supervoxel& s2) const {
+        float delta_c = 0;
+        const float* rgb1 = mean_color(s1);
+        const float* rgb2 = mean_color(s2);
+        if (prm.color_metric == F3DS_LAB_CIEDE00) {
+            float lab1[3], lab2[3];
+            rgb2lab(rgb1, lab1); rgb2lab(rgb2, lab2);
+            delta_c = lab_ciede00(lab1, lab2);
+            delta_c /= LAB_RANGE;
+        } else {
+            delta_c = rgb_eucl(rgb1, rgb2);
+            delta_c /= RGB_RANGE;
+        }
+        float delta_g = normals_diff(s1, s2);
+        if (prm.geom_metric == F3DS_CONVEX_NORMALS_DIFF && is_convex(s1, s2)) delta_g *= 0.5;
+        return {delta_c, delta_g};
+    }
+    // src/clustering.cpp:324-376
+    float t_c(float delta_c) {
+        if (prm.merging != F3DS_EQUALIZATION) return lambda * delta_c;
+        short bin = (short)std::floor(delta_c * bins_num);
+        if (bin == bins_num) bin--;
+        auto it = cdf_c.find(bin);
+        if (it == cdf_c.end()) { error = F3DS_ERR_EQ_BIN; return 0; }
+        return it->second / 2;
+    }
+    float t_g(float delta_g) {
+        if (prm.merging != F3DS_EQUALIZATION) return (1 - lambda) * delta_g;
+        short bin = (short)std::floor(delta_g * bins_num);
+        auto it = cdf_g.find(bin);                          // no clamp: map::at throws at delta_g == 1
+        if (it == cdf_g.end()) { error = F3DS_ERR_EQ_BIN; return 0; }
+        return it->second / 2;
+    }
+    float delta(Supervoxel& a, Supervoxel& b) {
+        std::pair<float, float> d = delta_c_g(a, b);
+        return t_c(d.first) + t_g(d.second);
+    }
+    // src/clustering.cpp:515-528
+    static float deltas_mean(const std::multiset<float>& deltas) {
+        float count = 0, mean_d = 0;
+        for (float d : deltas) { count++; mean_d = mean_d + (1 / count) * (d - mean_d); }
+        return mean_d;
+    }
+    // src/clustering.cpp:289-314
+    std::map<short, float> compute_cdf(const std::multiset<float>& dist) {
+        std::map<short, float> cdf;
+        std::vector<int> bins(bins_num > 0 ? bins_num : 0, 0);
+        int n = (int)dist.size();
+        for (float d : dist) {
+            short bin = (short)std::floor(d * bins_num);
+            if (bin == bins_num) bin--;
+            if (bin < 0 || bin >= bins_num) { error = F3DS_ERR_EQ_BIN; continue; }   // VLA overrun in the reference
+            bins[bin]++;
+        }
+        for (short i = 0; i < bins_num; i++) {
+            float v = 0;
+            for (short j = 0; j <= i; j++) v += bins[j];
+            v /= n;
+            cdf.insert({i, v});
+        }
+        return cdf;
+    }
+};
+
+int run_clustering(f3ds_oracle& o) {
+    const f3ds_params& prm = o.prm;
+    Clusterer cl; cl.prm = prm;
+    // main(): set_merging / set_lambda / set_bins_num  (src/supervoxel_clustering.cpp:415-423)
+    cl.lambda = 0.5f; cl.bins_num = 500;
+    if (prm.merging == F3DS_MANUAL_LAMBDA && prm.lambda != 0) {
+        if (prm.lambda < 0 || prm.lambda > 1) return F3DS_ERR_RANGE;
+        cl.lambda = prm.lambda;
+    }
+    if (prm.merging == F3DS_EQUALIZATION && prm.bins != 0) {
+        if (prm.bins < 0) return F3DS_ERR_RANGE;
+        cl.bins_num = (short)prm.bins;
+    }
+    // set_initialstate: clear_adjacency + adj2weight (src/clustering.cpp:605-612,476-486,193-207)
+    std::map<uint32_t, SvPtr> segments = o.initial_segments;
+    std::vector<std::pair<uint32_t, uint32_t>> init_edges;
+    for (auto& kv : o.adjacency) if (!(kv.first > kv.second)) init_edges.push_back(kv);   // weights all -1 => insertion order
+    // init_weights (src/clustering.cpp:212-251)
+    std::multiset<float> deltas_c, deltas_g;
+    std::vector<std::pair<float, float>> temp_deltas;
+    o.edges.clear(); o.edge_deltas.clear(); o.edge_weights.clear();
+    for (auto& e : init_edges) {
+        std::pair<float, float> d = cl.delta_c_g(*segments.at(e.first), *segments.at(e.second));
+        temp_deltas.push_back(d);
+        deltas_c.insert(d.first); deltas_g.insert(d.second);
+        o.edges.push_back(e.first); o.edges.push_back(e.second);
+        o.edge_deltas.push_back(d.first); o.edge_deltas.push_back(d.second);
+    }
+    if (prm.merging == F3DS_ADAPTIVE_LAMBDA) {
+        float mean_c = Clusterer::deltas_mean(deltas_c);
+        float mean_g = Clusterer::deltas_mean(deltas_g);
+        cl.lambda = mean_g / (mean_c + mean_g);
+    } else if (prm.merging == F3DS_EQUALIZATION) {
+        cl.cdf_c = cl.compute_cdf(deltas_c);
+        cl.cdf_g = cl.compute_cdf(deltas_g);
+    }
+    WeightMap weight_map;
+    for (size_t i = 0; i < init_edges.size(); ++i) {
+        float w = cl.t_c(temp_deltas[i].first) + cl.t_g(temp_deltas[i].second);
+        weight_map.insert({w, init_edges[i]});
+        o.edge_weights.push_back(w);
+    }
+    if (cl.error) return cl.error;
+    o.res.lambda = cl.lambda;
+    // cluster(initial_state, threshold)  (src/clustering.cpp:384-396)
+    o.merges.clear();
+    while (!weight_map.empty() && weight_map.begin()->first < prm.threshold) {
+        float wfirst = weight_map.begin()->first;
+        std::pair<uint32_t, uint32_t> ids = weight_map.begin()->second;
+        uint32_t wb; memcpy(&wb, &wfirst, 4);
+        o.merges.push_back(ids.first); o.merges.push_back(ids.second); o.merges.push_back(wb);
+        // merge (src/clustering.cpp:403-469)
+        SvPtr sup1 = segments.at(ids.first), sup2 = segments.at(ids.second);
+        SvPtr sn = std::make_shared<Supervoxel>();
+        sn->voxels = sup1->voxels; sn->voxels.insert(sn->voxels.end(), sup2->voxels.begin(), sup2->voxels.end());
+        sn->voxel_idx = sup1->voxel_idx; sn->voxel_idx.insert(sn->voxel_idx.end(), sup2->voxel_idx.begin(), sup2->voxel_idx.end());
+        sn->leaves = sup1->leaves; sn->leaves.insert(sn->leaves.end(), sup2->leaves.begin(), sup2->leaves.end());
+        // pcl::computeCentroid -> CentroidPoint: xyz = sum / n  [PCL-recall A9]
+        float sx = 0, sy = 0, sz = 0;
+        for (const SvPoint& v : sn->voxels) { sx += v.x; sy += v.y; sz += v.z; }
+        float nf = (float)sn->voxels.size();
+        sn->centroid[0] = sx / nf; sn->centroid[1] = sy / nf; sn->centroid[2] = sz / nf;
+        float n4[4], curv;
+        point_normal(sn->voxels.begin(), sn->voxels.end(), sn->voxels.size(),
+                     [](const SvPoint& v) { return XYZ{v.x, v.y, v.z}; }, sn->centroid, n4, &curv);
+        sn->normal[0] = n4[0]; sn->normal[1] = n4[1]; sn->normal[2] = n4[2];
+        segments.erase(ids.first); segments.erase(ids.second);
+        segments.insert({ids.first, sn});
+        WeightMap new_map;
+        std::set<std::pair<uint32_t, uint32_t>> present;        // same answer as contains() (:497-506)
+        auto it = weight_map.begin(); ++it;
+        for (; it != weight_map.end(); ++it) {
+            std::pair<uint32_t, uint32_t> cur = it->second;
+            bool touched = true;
+            if (cur.first == ids.first || cur.second == ids.first) {
+            } else if (cur.first == ids.second) {
+                cur.first = ids.first;
+            } else if (cur.second == ids.second) {
+                if (cur.first < ids.first) cur.second = ids.first;
+                else { cur.second = cur.first; cur.first = ids.first; }
+            } else touched = false;
+            if (touched) {
+                if (!present.count(cur)) {
+                    float w = cl.delta(*segments.at(cur.first), *segments.at(cur.second));
+                    new_map.insert({w, cur});
+                    present.insert(cur);
+                }
+            } else {
+                new_map.insert(*it);
+                present.insert(cur);
+            }
+        }
+        weight_map.swap(new_map);
+        if (cl.error) return cl.error;
+    }
+    o.segments = segments;
+    o.res.n_merges = (uint32_t)(o.merges.size() / 3);
+    o.res.n_regions = (uint32_t)segments.size();
+    return 0;
+}
+
+const uint32_t* glasbey_table();
+
+}  // namespace
+
+extern "C" {
+
+int f3ds_oracle_cluster(f3ds_oracle* o, const f3ds_params* prm, uint32_t* labels, f3ds_result* res);
+
+int f3ds_oracle_segment(const void* points16, size_t n, const f3ds_params* prm, uint32_t* labels, f3ds_result* res,
+                        f3ds_oracle** handle_out) {
+    if ((!points16 && n) || !prm) return F3DS_ERR_ARG;
+    auto t0 = std::chrono::steady_clock::now();
+    std::unique_ptr<f3ds_oracle> op(new f3ds_oracle);
+    f3ds_oracle& o = *op;
+    o.prm = *prm; o.n = n;
+    memset(&o.res, 0, sizeof(o.res));
+    o.res.n_points = n;
+    // main() prelude: z<0 -> |z|  (src/supervoxel_clustering.cpp:317-321)
+    std::vector<P16> pts(n);
+    if (n) memcpy(pts.data(), points16, n * sizeof(P16));
+    if (prm->fold_negative_z) for (P16& p : pts) if (p.z < 0) p.z = std::abs(p.z);
+    int rc = voxelise(o, pts);
+    if (rc) return rc;
+    o.res.n_voxels = (uint32_t)o.vox.size();
+    o.res.octree_depth = (uint32_t)o.cube.depth;
+    rc = select_seeds(o);
+    if (rc) return rc;
+    o.res.n_seed_cells = (uint32_t)o.seed_orig.size();
+    o.res.n_seeds = (uint32_t)o.seed_kept.size();
+    std::list<Helper> helpers;
+    expand_supervoxels(o, helpers);
+    // makeSupervoxels + getSupervoxelAdjacency
+    for (Helper& h : helpers) {
+        SvPtr s = std::make_shared<Supervoxel>();
+        for (int a = 0; a < 3; ++a) { s->centroid[a] = h.c.xyz[a]; s->normal[a] = h.c.normal[a]; }
+        for (int li : h.leaves) {
+            const Voxel& v = o.vox[li];
+            uint32_t c = v.rgba_trunc();
+            s->voxels.push_back(SvPoint{v.xyz[0], v.xyz[1], v.xyz[2], (uint8_t)((c >> 16) & 255), (uint8_t)((c >> 8) & 255), (uint8_t)(c & 255)});
+            s->voxel_idx.push_back(li);
+        }
+        s->leaves.push_back(h.label);
+        o.initial_segments[h.label] = s;
+        o.sv_labels.push_back(h.label);
+        for (int a = 0; a < 3; ++a) o.sv_centroid.push_back(h.c.xyz[a]);
+        for (int a = 0; a < 3; ++a) o.sv_centroid.push_back(h.c.rgb[a]);
+        for (int a = 0; a < 4; ++a) o.sv_centroid.push_back(h.c.normal[a]);
+        std::set<uint32_t> nl;
+        for (int li : h.leaves)
+            for (int nb : o.vox[li].nbrs) {
+                const Voxel& nv = o.vox[nb];
+                if (nv.owner != &h && nv.owner) nl.insert(nv.owner->label);
+            }
+        for (uint32_t l : nl) o.adjacency.insert({h.label, l});
+    }
+    o.res.n_supervoxels = (uint32_t)helpers.size();
+    // keep per-voxel label/dist, then drop the Helper pointers (the list dies with this frame)
+    for (Voxel& v : o.vox) { v.svlabel = v.owner ? v.owner->label : 0; v.owner = nullptr; }
+    rc = f3ds_oracle_cluster(&o, prm, labels, nullptr);
+    if (rc) return rc;
+    auto t1 = std::chrono::steady_clock::now();
+    o.res.ms_total = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (res) *res = o.res;
+    if (handle_out) *handle_out = op.release();
+    return 0;
+}
+
+// Clustering::cluster(threshold) on the stored supervoxels + per-point / per-voxel labels
+int f3ds_oracle_cluster(f3ds_oracle* op, const f3ds_params* prm, uint32_t* labels, f3ds_result* res) {
+    if (!op || !prm) return F3DS_ERR_ARG;
+    f3ds_oracle& o = *op;
+    o.prm.color_metric = prm->color_metric; o.prm.geom_metric = prm->geom_metric; o.prm.merging = prm->merging;
+    o.prm.lambda = prm->lambda; o.prm.bins = prm->bins; o.prm.threshold = prm->threshold;
+    for (auto& kv : o.initial_segments) kv.second->mean_valid = false;
+    int rc = run_clustering(o);
+    if (rc) return rc;
+    uint32_t nedges = (uint32_t)(o.edges.size() / 2);
+    o.res.n_edges = nedges;
+    // get_labeled_cloud numbering: running index over segments in ascending key (src/clustering.cpp:646-660)
+    std::map<uint32_t, uint32_t> rank_of_label, root_of_leaf;
+    uint32_t cur = 0;
+    o.voxel_region.assign(o.vox.size(), F3DS_NO_LABEL);
+    for (auto& kv : o.segments) {
+        for (int vi : kv.second->voxel_idx) o.voxel_region[vi] = cur;
+        for (uint32_t leaf : kv.second->leaves) root_of_leaf[leaf] = kv.first;
+        rank_of_label[kv.first] = cur++;
+    }
+    o.sv_region.clear();
+    for (uint32_t l : o.sv_labels) o.sv_region.push_back(root_of_leaf[l]);
+    if (labels)
+        for (size_t i = 0; i < o.n; ++i) labels[i] = o.point_voxel[i] >= 0 ? o.voxel_region[o.point_voxel[i]] : F3DS_NO_LABEL;
+    if (res) *res = o.res;
+    return 0;
+}
+
+int f3ds_oracle_voxel_cloud(f3ds_oracle* o, float* xyz, uint32_t* label, uint32_t* rgba, size_t cap, size_t* n_out) {
+    if (!o) return F3DS_ERR_ARG;
+    size_t k = 0; uint32_t cur = 0;
+    for (auto& kv : o->segments) {
+        for (const SvPoint& v : kv.second->voxels) {
+            if (k < cap) {
+                if (xyz) { xyz[3 * k] = v.x; xyz[3 * k + 1] = v.y; xyz[3 * k + 2] = v.z; }
+                if (label) label[k] = cur;
+                if (rgba) rgba[k] = glasbey_table()[cur % 256];
+            }
+            k++;
+        }
+        cur++;
+    }
+    if (n_out) *n_out = k;
+    return k > cap && (xyz || label || rgba) ? F3DS_ERR_CAPACITY : 0;
+}
+
+int f3ds_oracle_get(f3ds_oracle* o, int what, void* dst, size_t cap, size_t* bytes_out) {
+    if (!o) return F3DS_ERR_ARG;
+    std::vector<uint8_t> buf;
+    auto put = [&](const void* p, size_t nb) { const uint8_t* b = (const uint8_t*)p; buf.insert(buf.end(), b, b + nb); };
+    const size_t V = o->vox.size();
+    switch (what) {
+        case F3DS_DBG_GRID: { double g[5] = {o->cube.min[0], o->cube.min[1], o->cube.min[2], o->cube.res, (double)o->cube.depth}; put(g, sizeof g); break; }
+        case F3DS_DBG_VOXEL_KEYS: for (auto& v : o->vox) put(v.key, 12); break;
+        case F3DS_DBG_VOXEL_COUNT: for (auto& v : o->vox) put(&v.num_points, 4); break;
+        case F3DS_DBG_VOXEL_XYZ: for (auto& v : o->vox) put(v.xyz, 12); break;
+        case F3DS_DBG_VOXEL_RGB: for (auto& v : o->vox) put(v.rgb, 12); break;
+        case F3DS_DBG_VOXEL_NORMAL: for (auto& v : o->vox) put(v.normal, 16); break;
+        case F3DS_DBG_VOXEL_NEIGHBORS: for (auto& v : o->vox) put(v.nbr_slot, 27 * 4); break;
+        case F3DS_DBG_POINT_VOXEL: put(o->point_voxel.data(), o->point_voxel.size() * 4); break;
+        case F3DS_DBG_SEED_ORIG: put(o->seed_orig.data(), o->seed_orig.size() * 4); break;
+        case F3DS_DBG_SEED_KEPT: put(o->seed_kept.data(), o->seed_kept.size() * 4); break;
+        case F3DS_DBG_VOXEL_SVLABEL: for (auto& v : o->vox) put(&v.svlabel, 4); break;
+        case F3DS_DBG_VOXEL_DIST: for (auto& v : o->vox) put(&v.distance, 4); break;
+        case F3DS_DBG_SV_LABELS: put(o->sv_labels.data(), o->sv_labels.size() * 4); break;
+        case F3DS_DBG_SV_CENTROID: put(o->sv_centroid.data(), o->sv_centroid.size() * 4); break;
+        case F3DS_DBG_EDGES: put(o->edges.data(), o->edges.size() * 4); break;
+        case F3DS_DBG_EDGE_DELTAS: put(o->edge_deltas.data(), o->edge_deltas.size() * 4); break;
+        case F3DS_DBG_EDGE_WEIGHTS: put(o->edge_weights.data(), o->edge_weights.size() * 4); break;
+        case F3DS_DBG_MERGES: put(o->merges.data(), o->merges.size() * 4); break;
+        case F3DS_DBG_VOXEL_REGION: put(o->voxel_region.data(), V * 4); break;
+        case F3DS_DBG_SV_REGION: put(o->sv_region.data(), o->sv_region.size() * 4); break;
+        default: return F3DS_ERR_ARG;
+    }
+    if (bytes_out) *bytes_out = buf.size();
+    if (dst) {
+        if (buf.size() > cap) return F3DS_ERR_CAPACITY;
+        if (!buf.empty()) memcpy(dst, buf.data(), buf.size());
+    }
+    return 0;
+}
+
+void f3ds_oracle_free(f3ds_oracle* o) { delete o; }
+
+// known-answer-test entry points (tests/test_oracle.py)
+float f3ds_oracle_ciede00(const float* lab1, const float* lab2) { return lab_ciede00(lab1, lab2); }
+float f3ds_oracle_rgb_eucl(const float* a, const float* b) { return rgb_eucl(a, b); }
+void f3ds_oracle_rgb2lab(const float* rgb, float* lab) { rgb2lab(rgb, lab); }
+void f3ds_oracle_normal(const float* xyz, size_t n, const float* view_point, float* normal4) {
+    float curv;
+    std::vector<XYZ> pts(n);
+    for (size_t i = 0; i < n; ++i) pts[i] = XYZ{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    point_normal(pts.begin(), pts.end(), n, [](const XYZ& p) { return p; }, view_point, normal4, &curv);
+}
+// fn: 0 exp 1 log 2 sin 3 cos 4 atan2 5 cbrt 6 pow(a,b) 7 logf 8 atan2f 9 cosf 10 sinf   (shared-math probes)
+double f3ds_oracle_math(int fn, double a, double b) {
+    switch (fn) {
+        case 0: return f3ds::m_exp(a);
+        case 1: return f3ds::m_log(a);
+        case 2: return f3ds::m_sin(a);
+        case 3: return f3ds::m_cos(a);
+        case 4: return f3ds::m_atan2(a, b);
+        case 5: return f3ds::m_cbrt_pos(a);
+        case 6: return f3ds::m_pow_pos(a, b);
+        case 7: return (double)f3ds::m_logf((float)a);
+        case 8: return (double)f3ds::m_atan2f((float)a, (float)b);
+        case 9: return (double)f3ds::m_cosf((float)a);
+        case 10: return (double)f3ds::m_sinf((float)a);
+    }
+    return 0;
+}
+void f3ds_oracle_math_vec(int fn, const double* a, const double* b, double* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) out[i] = f3ds_oracle_math(fn, a[i], b ? b[i] : 0.0);
+}
+int f3ds_oracle_uses_libm(void) {
+#ifdef F3DS_ORACLE_LIBM
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+}  // extern "C"
+
+#include "../fast-3d-pointcloud-segmentation_amd/csrc/f3ds_glasbey.h"
+namespace { const uint32_t* glasbey_table() { return f3ds_glasbey_256; } }

@@ -1,0 +1,554 @@
+// f3ds_emul.cpp -- sequential CPU emulation of the DEVICE pipeline.  TEST INFRASTRUCTURE ONLY.
+//
+// It walks the same stages as fast-3d-pointcloud-segmentation_amd/csrc/f3ds_hip.hip and calls the very same
+// per-element functions (csrc/f3ds_numerics.h, csrc/f3ds_algo.h), but with plain loops where
+// the GPU uses threads.  Purpose: prove on a machine without a GPU that the data-parallel
+// reformulation (stable sort + ordered per-voxel sums, seed-grid events, R-predicate sweeps,
+// history-ordered merge) produces exactly what the literal oracle (oracle/f3ds_oracle.cpp)
+// produces.  It is never linked into libf3ds and nothing in the product calls it.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/f3ds.h"
+#include "../../fast-3d-pointcloud-segmentation_amd/csrc/f3ds_algo.h"
+#include "../../fast-3d-pointcloud-segmentation_amd/csrc/f3ds_glasbey.h"
+
+using namespace f3ds;
+
+namespace {
+struct P16 { float x, y, z; uint32_t rgba; };
+}
+
+struct f3ds_emul {
+    f3ds_params prm;
+    size_t n = 0;
+    GridInfo grid;
+    int V = 0;
+    std::vector<uint32_t> vkey;      // V x 3
+    std::vector<uint32_t> vcount;    // V
+    std::vector<float> vf;           // V x 12
+    std::vector<int> nbr;            // V x 27
+    std::vector<int> point_voxel;
+    std::vector<int> seed_orig, seed_kept;
+    std::vector<uint32_t> owner;
+    std::vector<float> dist;
+    std::vector<float> hc;           // (S0+1) x 12
+    std::vector<uint32_t> hcount;    // S0+1
+    std::vector<int> ghost_vox;      // S0+1: seed voxel the helper holds without owning it, -1 = none
+    std::vector<uint8_t> ghost_active;
+    std::vector<uint32_t> sv_labels;
+    std::vector<float> sv_centroid;
+    std::vector<uint32_t> edges;
+    std::vector<float> edge_deltas, edge_weights;
+    std::vector<uint32_t> merges;
+    std::vector<uint32_t> voxel_region, sv_region;
+    // supervoxel payload
+    std::vector<float> rows;         // sum(len) x 12
+    std::vector<int> row_voxel;
+    std::vector<uint32_t> loff, llen;   // per label
+    // merge state kept for the voxel-cloud accessor
+    std::vector<uint32_t> rhead, lnext;
+    std::vector<uint8_t> ralive;
+    f3ds_result res;
+};
+
+namespace {
+
+int stage_voxels(f3ds_emul& E, const std::vector<P16>& pts) {
+    const f3ds_params& prm = E.prm;
+    const size_t n = pts.size();
+    float mn[3] = {F3DS_FLT_MAX, F3DS_FLT_MAX, F3DS_FLT_MAX}, mx[3] = {-F3DS_FLT_MAX, -F3DS_FLT_MAX, -F3DS_FLT_MAX};
+    size_t nb = 0; E.res.n_finite = 0;
+    for (size_t i = 0; i < n; ++i) {
+        float x = pts[i].x, y = pts[i].y, z = pts[i].z;
+        n_prelude(z, prm.fold_negative_z);
+        if (n_finite3(x, y, z)) E.res.n_finite++;
+        n_transform(x, y, z, prm.use_transform);
+        if (!n_finite3(x, y, z)) continue;
+        if (x < mn[0]) mn[0] = x; if (y < mn[1]) mn[1] = y; if (z < mn[2]) mn[2] = z;
+        if (x > mx[0]) mx[0] = x; if (y > mx[1]) mx[1] = y; if (z > mx[2]) mx[2] = z;
+        nb++;
+    }
+    E.point_voxel.assign(n, -1);
+    if (nb == 0) { memset(&E.grid, 0, sizeof E.grid); E.grid.res = prm.voxel_res; E.grid.empty = 1; E.V = 0; return 0; }
+    n_grid_from_bbox(mn, mx, prm.voxel_res, E.grid);
+    if (E.grid.error) return E.grid.error;
+    const int depth = E.grid.depth;
+    const uint64_t invalid = 1ull << (3 * depth);
+    const uint64_t mask = invalid - 1;
+    std::vector<std::pair<uint64_t, uint32_t>> kv(n);
+    for (size_t i = 0; i < n; ++i) {
+        float x = pts[i].x, y = pts[i].y, z = pts[i].z;
+        n_prelude(z, prm.fold_negative_z);
+        uint64_t key = invalid;
+        if (n_finite3(x, y, z)) {
+            unsigned k[3];
+            n_point_key(E.grid, x, y, z, prm.use_transform, k);
+            key = n_morton(k[0], k[1], k[2], depth);
+            if (prm.leaf_order == 1) key = (~key) & mask;
+        }
+        kv[i] = {key, (uint32_t)i};
+    }
+    std::stable_sort(kv.begin(), kv.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; });
+    size_t nvalid = 0;
+    while (nvalid < n && kv[nvalid].first != invalid) nvalid++;
+    std::vector<size_t> start;
+    for (size_t i = 0; i < nvalid; ++i) if (i == 0 || kv[i].first != kv[i - 1].first) start.push_back(i);
+    const int V = (int)start.size();
+    start.push_back(nvalid);
+    E.V = V;
+    E.vkey.resize((size_t)V * 3); E.vcount.resize(V); E.vf.assign((size_t)V * 12, 0.0f);
+    for (int v = 0; v < V; ++v) {           // one lane per voxel on the device
+        float sx = 0, sy = 0, sz = 0, sr = 0, sg = 0, sb = 0;
+        for (size_t i = start[v]; i < start[v + 1]; ++i) {
+            const P16& p = pts[kv[i].second];
+            float z = p.z; n_prelude(z, prm.fold_negative_z);
+            sx += p.x; sy += p.y; sz += z;
+            sr += (float)((p.rgba >> 16) & 255u); sg += (float)((p.rgba >> 8) & 255u); sb += (float)(p.rgba & 255u);
+            E.point_voxel[kv[i].second] = v;
+        }
+        unsigned cnt = (unsigned)(start[v + 1] - start[v]);
+        float c = (float)cnt;
+        float* f = &E.vf[(size_t)v * 12];
+        f[0] = sx / c; f[1] = sy / c; f[2] = sz / c; f[3] = sr / c; f[4] = sg / c; f[5] = sb / c;
+        E.vcount[v] = cnt;
+        uint64_t code = kv[start[v]].first;
+        if (prm.leaf_order == 1) code = (~code) & mask;
+        n_demorton(code, depth, &E.vkey[(size_t)v * 3]);
+    }
+    std::unordered_map<uint64_t, int> table;
+    table.reserve((size_t)V * 2);
+    for (int v = 0; v < V; ++v) table.emplace(n_pack_key(E.vkey[v * 3], E.vkey[v * 3 + 1], E.vkey[v * 3 + 2]), v);
+    E.nbr.assign((size_t)V * 27, -1);
+    for (int v = 0; v < V; ++v)
+        for (int s = 0; s < 27; ++s) {
+            int d[3] = {s / 9 - 1, (s / 3) % 3 - 1, s % 3 - 1};
+            bool ok = true; unsigned k[3];
+            for (int a = 0; a < 3; ++a) {
+                int64_t q = (int64_t)E.vkey[v * 3 + a] + d[a];
+                if (q < 0 || q > (int64_t)E.grid.max_key) ok = false;
+                k[a] = (unsigned)q;
+            }
+            if (!ok) continue;
+            auto it = table.find(n_pack_key(k[0], k[1], k[2]));
+            if (it != table.end()) E.nbr[(size_t)v * 27 + s] = it->second;
+        }
+    for (int v = 0; v < V; ++v) {           // normals: self, then each neighbour followed by its neighbours
+        float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned cnt = 0;
+        auto add = [&](int u) {
+            const float* q = &E.vf[(size_t)u * 12];
+            acc[0] += q[0] * q[0]; acc[1] += q[0] * q[1]; acc[2] += q[0] * q[2];
+            acc[3] += q[1] * q[1]; acc[4] += q[1] * q[2]; acc[5] += q[2] * q[2];
+            acc[6] += q[0]; acc[7] += q[1]; acc[8] += q[2];
+            cnt++;
+        };
+        add(v);
+        for (int s = 0; s < 27; ++s) {
+            int u = E.nbr[(size_t)v * 27 + s];
+            if (u < 0) continue;
+            add(u);
+            for (int s2 = 0; s2 < 27; ++s2) { int u2 = E.nbr[(size_t)u * 27 + s2]; if (u2 >= 0) add(u2); }
+        }
+        float n4[4];
+        n_plane_normal(acc, cnt, &E.vf[(size_t)v * 12], n4);
+        E.vf[(size_t)v * 12 + 6] = n4[0]; E.vf[(size_t)v * 12 + 7] = n4[1]; E.vf[(size_t)v * 12 + 8] = n4[2];
+    }
+    return 0;
+}
+
+int stage_seeds(f3ds_emul& E) {
+    const f3ds_params& prm = E.prm;
+    const int V = E.V;
+    E.seed_orig.clear(); E.seed_kept.clear();
+    if (V == 0) return 0;
+    SeedGrid g; a_seed_init(g, prm.seed_res);
+    for (int i = 0; i < V; ++i) {           // device: chunk bounding boxes + first-violation search per event
+        const float* p = &E.vf[(size_t)i * 12];
+        if (a_seed_violates(g, p)) a_seed_grow(g, i, p);
+        if (g.error) return g.error;
+    }
+    std::vector<unsigned> ck((size_t)V * 3);
+    std::vector<std::pair<uint64_t, int>> order(V);
+    for (int i = 0; i < V; ++i) {
+        a_seed_key(g, i, &E.vf[(size_t)i * 12], &ck[(size_t)i * 3]);
+        order[i] = {n_morton(ck[i * 3], ck[i * 3 + 1], ck[i * 3 + 2], g.depth), i};
+    }
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<uint64_t, int>& a, const std::pair<uint64_t, int>& b) { return a.first < b.first; });
+    std::vector<int> cstart;
+    for (int i = 0; i < V; ++i) if (i == 0 || order[i].first != order[i - 1].first) cstart.push_back(i);
+    const int C = (int)cstart.size();
+    cstart.push_back(V);
+    std::unordered_map<uint64_t, int> cell_of;
+    for (int c = 0; c < C; ++c) { int v = order[cstart[c]].second; cell_of.emplace(n_pack_key(ck[v * 3], ck[v * 3 + 1], ck[v * 3 + 2]), c); }
+    auto for_block = [&](const unsigned key[3], auto&& fn) {
+        for (int dx = -1; dx <= 1; ++dx) for (int dy = -1; dy <= 1; ++dy) for (int dz = -1; dz <= 1; ++dz) {
+            int64_t x = (int64_t)key[0] + dx, y = (int64_t)key[1] + dy, z = (int64_t)key[2] + dz;
+            if (x < 0 || y < 0 || z < 0) continue;
+            auto it = cell_of.find(n_pack_key((unsigned)x, (unsigned)y, (unsigned)z));
+            if (it == cell_of.end()) continue;
+            for (int i = cstart[it->second]; i < cstart[it->second + 1]; ++i) fn(order[i].second);
+        }
+    };
+    E.seed_orig.resize(C);
+    for (int c = 0; c < C; ++c) {
+        int v0 = order[cstart[c]].second;
+        float centre[3]; a_seed_centre(g, &ck[(size_t)v0 * 3], centre);
+        int best = -1; float bd = 0;
+        for_block(&ck[(size_t)v0 * 3], [&](int j) {
+            float d = a_sqdist(centre, &E.vf[(size_t)j * 12]);
+            if (best < 0 || d < bd || (d == bd && j < best)) { best = j; bd = d; }
+        });
+        E.seed_orig[c] = best;
+    }
+    float min_points = a_min_points(prm.seed_res, prm.voxel_res);
+    float r2 = a_radius_sq(prm.seed_res);
+    for (int c = 0; c < C; ++c) {
+        int s = E.seed_orig[c];
+        int num = 0;
+        for_block(&ck[(size_t)s * 3], [&](int j) { if (a_sqdist(&E.vf[(size_t)s * 12], &E.vf[(size_t)j * 12]) < r2) num++; });
+        if ((float)num > min_points) E.seed_kept.push_back(s);
+    }
+    return 0;
+}
+
+int stage_sweeps(f3ds_emul& E) {
+    const f3ds_params& prm = E.prm;
+    const int V = E.V;
+    const int S0 = (int)E.seed_kept.size();
+    E.owner.assign(V, 0u); E.dist.assign(V, F3DS_FLT_MAX);
+    E.hc.assign((size_t)(S0 + 1) * 12, 0.0f); E.hcount.assign(S0 + 1, 0u);
+    E.ghost_vox.assign(S0 + 1, -1); E.ghost_active.assign(S0 + 1, 0);
+    for (int i = 0; i < S0; ++i) {          // createSupervoxelHelpers: addLeaf overwrites owner_
+        int v = E.seed_kept[i];
+        if (E.owner[v] != 0u) { E.ghost_vox[E.owner[v]] = v; E.ghost_active[E.owner[v]] = 1; }
+        E.owner[v] = (uint32_t)(i + 1);
+        E.hcount[i + 1] = 1;
+    }
+    int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
+    E.res.sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0u;
+    std::vector<unsigned char> R(V), done(S0 + 1);
+    std::vector<uint32_t> owner2(V), ghost_head(V, 0u), ghost_next(S0 + 1, 0u);
+    std::vector<float> dist2(V);
+    for (uint32_t t = 0; t < E.res.sweeps; ++t) {
+        for (int h = 1; h <= S0; ++h) if (E.ghost_vox[h] >= 0) ghost_head[E.ghost_vox[h]] = 0u;
+        for (int h = 1; h <= S0; ++h) if (E.ghost_active[h]) { ghost_next[h] = ghost_head[E.ghost_vox[h]]; ghost_head[E.ghost_vox[h]] = (uint32_t)h; }
+        SweepView s{V, E.nbr.data(), E.vf.data(), E.owner.data(), E.dist.data(), E.hc.data(), ghost_head.data(), ghost_next.data(),
+                    prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
+        int overflow = 0;
+        for (int v = 0; v < V; ++v) R[v] = E.owner[v] ? (unsigned char)a_eval_R(s, v, &overflow) : 0;
+        if (overflow) return F3DS_ERR_UNSUPPORTED;
+        std::fill(done.begin(), done.end(), 0);
+        for (int v = 0; v < V; ++v) a_claim(s, R.data(), v, &owner2[v], &dist2[v], done.data());
+        E.owner.swap(owner2); E.dist.swap(dist2);
+        for (int h = 1; h <= S0; ++h) if (done[h]) E.ghost_active[h] = 0;
+        std::vector<float> sum((size_t)(S0 + 1) * 9, 0.0f);
+        std::fill(E.hcount.begin(), E.hcount.end(), 0u);
+        std::map<int, std::vector<int>> gmap;
+        for (int h = 1; h <= S0; ++h) if (E.ghost_active[h]) gmap[E.ghost_vox[h]].push_back(h);
+        auto add = [&](uint32_t h, int v) {
+            const float* f = &E.vf[(size_t)v * 12];
+            float* q = &sum[(size_t)h * 9];
+            for (int k = 0; k < 9; ++k) q[k] += f[k];
+            E.hcount[h]++;
+        };
+        for (int v = 0; v < V; ++v) {       // ascending ordinal = SupervoxelHelper leaf order
+            uint32_t h = E.owner[v];
+            if (h) add(h, v);
+            if (!gmap.empty()) { auto it = gmap.find(v); if (it != gmap.end()) for (int g : it->second) add((uint32_t)g, v); }
+        }
+        for (int h = 1; h <= S0; ++h) if (E.hcount[h]) a_centroid_finish(&sum[(size_t)h * 9], E.hcount[h], &E.hc[(size_t)h * 12]);
+    }
+    return 0;
+}
+
+int stage_merge(f3ds_emul& E) {
+    const f3ds_params& prm = E.prm;
+    const int V = E.V;
+    const int S0 = (int)E.seed_kept.size();
+    // supervoxel payload rows, leaf sums
+    E.sv_labels.clear(); E.sv_centroid.clear();
+    E.loff.assign(S0 + 1, 0u); E.llen.assign(S0 + 1, 0u);
+    std::map<int, std::vector<int>> gmap;   // voxel -> helpers that keep it as a ghost leaf
+    for (int h = 1; h <= S0; ++h) if (E.ghost_active[h]) gmap[E.ghost_vox[h]].push_back(h);
+    for (int v = 0; v < V; ++v) if (E.owner[v]) E.llen[E.owner[v]]++;
+    for (auto& kv : gmap) for (int g : kv.second) E.llen[g]++;
+    uint32_t run = 0;
+    for (int h = 1; h <= S0; ++h) { E.loff[h] = run; run += E.llen[h]; }
+    E.rows.assign((size_t)run * 12, 0.0f); E.row_voxel.assign(run, -1);
+    std::vector<uint32_t> fill(S0 + 1, 0u);
+    auto put_row = [&](uint32_t h, int v) {
+        uint32_t r = E.loff[h] + fill[h]++;
+        a_payload_row(&E.vf[(size_t)v * 12], &E.rows[(size_t)r * 12]);
+        E.row_voxel[r] = v;
+    };
+    for (int v = 0; v < V; ++v) {
+        if (E.owner[v]) put_row(E.owner[v], v);
+        if (!gmap.empty()) { auto it = gmap.find(v); if (it != gmap.end()) for (int g : it->second) put_row((uint32_t)g, v); }
+    }
+    std::vector<float> racc((size_t)(S0 + 1) * 12, 0.0f), rrec((size_t)(S0 + 1) * 16, 0.0f);
+    std::vector<uint32_t> rcnt(S0 + 1, 0u);
+    E.ralive.assign(S0 + 1, 0); E.rhead.assign(S0 + 1, 0u); E.lnext.assign(S0 + 1, 0u);
+    std::vector<uint32_t> rtail(S0 + 1, 0u);
+    for (int h = 1; h <= S0; ++h) {
+        if (!E.llen[h]) continue;
+        E.ralive[h] = 1; E.rhead[h] = rtail[h] = (uint32_t)h; rcnt[h] = E.llen[h];
+        float* acc = &racc[(size_t)h * 12];
+        for (uint32_t j = 0; j < E.llen[h]; ++j) a_fold_row(acc, &E.rows[(size_t)(E.loff[h] + j) * 12], j + 1);
+        float* rec = &rrec[(size_t)h * 16];
+        const float* c = &E.hc[(size_t)h * 12];
+        rec[0] = c[0]; rec[1] = c[1]; rec[2] = c[2]; rec[3] = c[6]; rec[4] = c[7]; rec[5] = c[8];
+        rec[6] = acc[9]; rec[7] = acc[10]; rec[8] = acc[11];
+        n_rgb2lab(rec + 6, rec + 9);
+        E.sv_labels.push_back((uint32_t)h);
+        for (int k = 0; k < 6; ++k) E.sv_centroid.push_back(c[k]);
+        for (int k = 6; k < 9; ++k) E.sv_centroid.push_back(c[k]);
+        E.sv_centroid.push_back(0.0f);
+    }
+    E.res.n_supervoxels = (uint32_t)E.sv_labels.size();
+    // adjacency (a<b), sorted unique
+    std::set<std::pair<uint32_t, uint32_t>> es;
+    auto leaf_edges = [&](uint32_t h, int v) {   // getNeighborLabels seen from one leaf of h
+        for (int s = 0; s < 27; ++s) {
+            int u = E.nbr[(size_t)v * 27 + s];
+            if (u < 0) continue;
+            uint32_t o = E.owner[u];
+            if (o && o != h && h < o) es.insert({h, o});
+        }
+    };
+    for (int v = 0; v < V; ++v) if (E.owner[v]) leaf_edges(E.owner[v], v);
+    for (auto& kv : gmap) for (int g : kv.second) leaf_edges((uint32_t)g, kv.first);
+    const int NE = (int)es.size();
+    std::vector<uint32_t> ea(NE), eb(NE);
+    { int i = 0; for (auto& p : es) { ea[i] = p.first; eb[i] = p.second; i++; } }
+    E.edges.clear(); E.edge_deltas.assign((size_t)NE * 2, 0.0f); E.edge_weights.assign(NE, 0.0f);
+    for (int e = 0; e < NE; ++e) { E.edges.push_back(ea[e]); E.edges.push_back(eb[e]); }
+    E.res.n_edges = (uint32_t)NE;
+    // merging parameters (main(): src/supervoxel_clustering.cpp:415-423; Clustering::set_merging :562-567)
+    float lambda = 0.5f; int bins = 500;
+    if (prm.merging == F3DS_MANUAL_LAMBDA && prm.lambda != 0) { if (prm.lambda < 0 || prm.lambda > 1) return F3DS_ERR_RANGE; lambda = prm.lambda; }
+    if (prm.merging == F3DS_EQUALIZATION && prm.bins != 0) { if (prm.bins < 0) return F3DS_ERR_RANGE; bins = (short)prm.bins; }
+    for (int e = 0; e < NE; ++e)
+        n_delta_c_g(&rrec[(size_t)ea[e] * 16], &rrec[(size_t)eb[e] * 16], prm.color_metric, prm.geom_metric, &E.edge_deltas[e * 2], &E.edge_deltas[e * 2 + 1]);
+    std::vector<float> cdf_c, cdf_g;
+    int err = 0;
+    if (prm.merging == F3DS_ADAPTIVE_LAMBDA) {
+        float mean[2];
+        for (int w = 0; w < 2; ++w) {
+            std::vector<uint32_t> keys(NE);
+            std::vector<float> vals(NE);
+            for (int e = 0; e < NE; ++e) vals[e] = E.edge_deltas[e * 2 + w];
+            // multiset<float> iteration order; NaN after every number like the weight map fence
+            std::stable_sort(vals.begin(), vals.end(), [](float a, float b) { return n_weight_key(a) < n_weight_key(b); });
+            float count = 0, m = 0;
+            for (float d : vals) { count++; m = m + (1 / count) * (d - m); }
+            mean[w] = m;
+        }
+        lambda = mean[1] / (mean[0] + mean[1]);
+    } else if (prm.merging == F3DS_EQUALIZATION) {
+        for (int w = 0; w < 2; ++w) {
+            std::vector<int> hist(bins > 0 ? bins : 0, 0);
+            for (int e = 0; e < NE; ++e) {
+                float d = E.edge_deltas[e * 2 + w];
+                short bin = (short)__builtin_floorf(d * (float)(short)bins);
+                if (bin == (short)bins) bin--;
+                if (bin < 0 || bin >= bins) { err = F3DS_ERR_EQ_BIN; continue; }
+                hist[bin]++;
+            }
+            std::vector<float>& cdf = w == 0 ? cdf_c : cdf_g;
+            cdf.resize(hist.size());
+            float v = 0;
+            for (size_t i = 0; i < hist.size(); ++i) { v += (float)hist[i]; cdf[i] = v / (float)NE; }
+        }
+    }
+    if (err) return err;
+    E.res.lambda = lambda;
+    MergeParams mp{prm.color_metric, prm.geom_metric, prm.merging, lambda, bins, cdf_c.data(), cdf_g.data()};
+    std::vector<float> ew(NE); std::vector<uint32_t> eku(NE); std::vector<int> ehist(NE); std::vector<uint8_t> ealive(NE, 1);
+    std::vector<uint32_t> ev_epoch, ev_key; std::vector<int> ev_prev;
+    for (int e = 0; e < NE; ++e) {
+        float w = a_tc(mp, E.edge_deltas[e * 2], &err) + a_tg(mp, E.edge_deltas[e * 2 + 1], &err);
+        ew[e] = w; eku[e] = n_weight_key(w); E.edge_weights[e] = w;
+        ehist[e] = (int)ev_epoch.size(); ev_epoch.push_back(0u); ev_key.push_back(eku[e]); ev_prev.push_back(-1);
+    }
+    if (err) return err;
+    E.merges.clear();
+    for (uint32_t epoch = 1;; ++epoch) {
+        EdgeHist H{ev_epoch.data(), ev_key.data(), ev_prev.data()};
+        int best = -1;
+        for (int e = 0; e < NE; ++e) {      // device: wave-parallel argmin with the same comparator
+            if (!ealive[e]) continue;
+            if (best < 0 || a_edge_before(H, (uint32_t)e, eku[e], ehist[e], (uint32_t)best, eku[best], ehist[best])) best = e;
+        }
+        if (best < 0 || !(ew[best] < prm.threshold)) break;
+        const uint32_t a = ea[best], b = eb[best];
+        uint32_t wb; memcpy(&wb, &ew[best], 4);
+        E.merges.push_back(a); E.merges.push_back(b); E.merges.push_back(wb);
+        ealive[best] = 0;
+        // fold b's voxels (rope order) into a's sums
+        float* acc = &racc[(size_t)a * 12];
+        uint32_t cnt = rcnt[a];
+        for (uint32_t leaf = E.rhead[b]; leaf; leaf = E.lnext[leaf])
+            for (uint32_t j = 0; j < E.llen[leaf]; ++j) a_fold_row(acc, &E.rows[(size_t)(E.loff[leaf] + j) * 12], ++cnt);
+        rcnt[a] = cnt;
+        E.lnext[rtail[a]] = E.rhead[b]; rtail[a] = rtail[b];
+        E.ralive[b] = 0;
+        a_region_from_acc(acc, cnt, &rrec[(size_t)a * 16]);
+        // incident edges: remap, drop the later duplicate, re-weight
+        std::vector<int> touched;
+        for (int e = 0; e < NE; ++e) if (ealive[e] && (ea[e] == a || eb[e] == a || ea[e] == b || eb[e] == b)) touched.push_back(e);
+        std::unordered_map<uint32_t, int> by_other;
+        std::vector<int> kept;
+        for (int e : touched) {
+            uint32_t x = (ea[e] == a || ea[e] == b) ? eb[e] : ea[e];
+            auto it = by_other.find(x);
+            if (it == by_other.end()) { by_other[x] = e; continue; }
+            int f = it->second;               // (a,x) and (b,x) both exist: the earlier map entry survives
+            if (a_edge_before(H, (uint32_t)e, eku[e], ehist[e], (uint32_t)f, eku[f], ehist[f])) { ealive[f] = 0; it->second = e; }
+            else ealive[e] = 0;
+        }
+        for (int e : touched) if (ealive[e]) kept.push_back(e);
+        for (int e : kept) {
+            uint32_t x = (ea[e] == a || ea[e] == b) ? eb[e] : ea[e];
+            uint32_t lo = a < x ? a : x, hi = a < x ? x : a;
+            ea[e] = lo; eb[e] = hi;
+            float w = a_edge_weight(mp, &rrec[(size_t)lo * 16], &rrec[(size_t)hi * 16], &err);
+            ew[e] = w; eku[e] = n_weight_key(w);
+            ev_epoch.push_back(epoch); ev_key.push_back(eku[e]); ev_prev.push_back(ehist[e]);
+            ehist[e] = (int)ev_epoch.size() - 1;
+        }
+        if (err) return err;
+    }
+    E.res.n_merges = (uint32_t)(E.merges.size() / 3);
+    // region ids: ascending surviving label (Clustering::get_labeled_cloud)
+    std::vector<uint32_t> rank(S0 + 1, F3DS_NO_LABEL), root(S0 + 1, 0u);
+    uint32_t k = 0;
+    for (int h = 1; h <= S0; ++h) if (E.ralive[h]) { rank[h] = k++; for (uint32_t leaf = E.rhead[h]; leaf; leaf = E.lnext[leaf]) root[leaf] = (uint32_t)h; }
+    E.res.n_regions = k;
+    E.voxel_region.assign(V, F3DS_NO_LABEL);
+    for (int v = 0; v < V; ++v) if (E.owner[v]) E.voxel_region[v] = rank[root[E.owner[v]]];
+    E.sv_region.clear();
+    for (uint32_t l : E.sv_labels) E.sv_region.push_back(root[l]);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int f3ds_emul_cluster(f3ds_emul* E, const f3ds_params* prm, uint32_t* labels, f3ds_result* res) {
+    if (!E || !prm) return F3DS_ERR_ARG;
+    E->prm.color_metric = prm->color_metric; E->prm.geom_metric = prm->geom_metric; E->prm.merging = prm->merging;
+    E->prm.lambda = prm->lambda; E->prm.bins = prm->bins; E->prm.threshold = prm->threshold;
+    int rc = stage_merge(*E);
+    if (rc) return rc;
+    if (labels) for (size_t i = 0; i < E->n; ++i) labels[i] = E->point_voxel[i] >= 0 ? E->voxel_region[E->point_voxel[i]] : F3DS_NO_LABEL;
+    if (res) *res = E->res;
+    return 0;
+}
+
+int f3ds_emul_segment(const void* points16, size_t n, const f3ds_params* prm, uint32_t* labels, f3ds_result* res, f3ds_emul** out) {
+    if ((!points16 && n) || !prm) return F3DS_ERR_ARG;
+    std::unique_ptr<f3ds_emul> Ep(new f3ds_emul);
+    f3ds_emul& E = *Ep;
+    E.prm = *prm; E.n = n;
+    memset(&E.res, 0, sizeof E.res);
+    E.res.n_points = n;
+    std::vector<P16> pts(n);
+    if (n) memcpy(pts.data(), points16, n * 16);
+    int rc = stage_voxels(E, pts);
+    if (rc) return rc;
+    E.res.n_voxels = (uint32_t)E.V; E.res.octree_depth = (uint32_t)E.grid.depth;
+    rc = stage_seeds(E);
+    if (rc) return rc;
+    E.res.n_seed_cells = (uint32_t)E.seed_orig.size(); E.res.n_seeds = (uint32_t)E.seed_kept.size();
+    rc = stage_sweeps(E);
+    if (rc) return rc;
+    rc = f3ds_emul_cluster(&E, prm, labels, nullptr);
+    if (rc) return rc;
+    if (res) *res = E.res;
+    if (out) *out = Ep.release();
+    return 0;
+}
+
+int f3ds_emul_voxel_cloud(f3ds_emul* E, float* xyz, uint32_t* label, uint32_t* rgba, size_t cap, size_t* n_out) {
+    if (!E) return F3DS_ERR_ARG;
+    size_t k = 0; uint32_t cur = 0;
+    for (size_t h = 1; h < E->ralive.size(); ++h) {
+        if (!E->ralive[h]) continue;
+        for (uint32_t leaf = E->rhead[h]; leaf; leaf = E->lnext[leaf])
+            for (uint32_t j = 0; j < E->llen[leaf]; ++j) {
+                if (k < cap) {
+                    const float* r = &E->rows[(size_t)(E->loff[leaf] + j) * 12];
+                    if (xyz) { xyz[3 * k] = r[6]; xyz[3 * k + 1] = r[7]; xyz[3 * k + 2] = r[8]; }
+                    if (label) label[k] = cur;
+                    if (rgba) rgba[k] = f3ds_glasbey_256[cur % 256];
+                }
+                k++;
+            }
+        cur++;
+    }
+    if (n_out) *n_out = k;
+    return k > cap && (xyz || label || rgba) ? F3DS_ERR_CAPACITY : 0;
+}
+
+int f3ds_emul_get(f3ds_emul* E, int what, void* dst, size_t cap, size_t* bytes_out) {
+    if (!E) return F3DS_ERR_ARG;
+    std::vector<uint8_t> buf;
+    auto put = [&](const void* p, size_t nb) { const uint8_t* b = (const uint8_t*)p; buf.insert(buf.end(), b, b + nb); };
+    const int V = E->V;
+    switch (what) {
+        case F3DS_DBG_GRID: { double g[5] = {E->grid.min[0], E->grid.min[1], E->grid.min[2], E->grid.res, (double)E->grid.depth}; put(g, sizeof g); break; }
+        case F3DS_DBG_VOXEL_KEYS: put(E->vkey.data(), E->vkey.size() * 4); break;
+        case F3DS_DBG_VOXEL_COUNT: put(E->vcount.data(), E->vcount.size() * 4); break;
+        case F3DS_DBG_VOXEL_XYZ: for (int v = 0; v < V; ++v) put(&E->vf[(size_t)v * 12], 12); break;
+        case F3DS_DBG_VOXEL_RGB: for (int v = 0; v < V; ++v) put(&E->vf[(size_t)v * 12 + 3], 12); break;
+        case F3DS_DBG_VOXEL_NORMAL: for (int v = 0; v < V; ++v) { float n4[4] = {E->vf[(size_t)v * 12 + 6], E->vf[(size_t)v * 12 + 7], E->vf[(size_t)v * 12 + 8], 0.0f}; put(n4, 16); } break;
+        case F3DS_DBG_VOXEL_NEIGHBORS: put(E->nbr.data(), E->nbr.size() * 4); break;
+        case F3DS_DBG_POINT_VOXEL: put(E->point_voxel.data(), E->point_voxel.size() * 4); break;
+        case F3DS_DBG_SEED_ORIG: put(E->seed_orig.data(), E->seed_orig.size() * 4); break;
+        case F3DS_DBG_SEED_KEPT: put(E->seed_kept.data(), E->seed_kept.size() * 4); break;
+        case F3DS_DBG_VOXEL_SVLABEL: put(E->owner.data(), E->owner.size() * 4); break;
+        case F3DS_DBG_VOXEL_DIST: put(E->dist.data(), E->dist.size() * 4); break;
+        case F3DS_DBG_SV_LABELS: put(E->sv_labels.data(), E->sv_labels.size() * 4); break;
+        case F3DS_DBG_SV_CENTROID: put(E->sv_centroid.data(), E->sv_centroid.size() * 4); break;
+        case F3DS_DBG_EDGES: put(E->edges.data(), E->edges.size() * 4); break;
+        case F3DS_DBG_EDGE_DELTAS: put(E->edge_deltas.data(), E->edge_deltas.size() * 4); break;
+        case F3DS_DBG_EDGE_WEIGHTS: put(E->edge_weights.data(), E->edge_weights.size() * 4); break;
+        case F3DS_DBG_MERGES: put(E->merges.data(), E->merges.size() * 4); break;
+        case F3DS_DBG_VOXEL_REGION: put(E->voxel_region.data(), E->voxel_region.size() * 4); break;
+        case F3DS_DBG_SV_REGION: put(E->sv_region.data(), E->sv_region.size() * 4); break;
+        default: return F3DS_ERR_ARG;
+    }
+    if (bytes_out) *bytes_out = buf.size();
+    if (dst) {
+        if (buf.size() > cap) return F3DS_ERR_CAPACITY;
+        if (!buf.empty()) memcpy(dst, buf.data(), buf.size());
+    }
+    return 0;
+}
+
+void f3ds_emul_free(f3ds_emul* E) { delete E; }
+
+// numerics probes for tests/test_numerics.py (device arithmetic evaluated on the host)
+float f3ds_emul_ciede00(const float* l1, const float* l2) { return n_ciede00(l1, l2); }
+float f3ds_emul_rgb_eucl(const float* a, const float* b) { return n_rgb_eucl(a, b); }
+void f3ds_emul_rgb2lab(const float* rgb, float* lab) { n_rgb2lab(rgb, lab); }
+void f3ds_emul_normal(const float* xyz, size_t n, const float* view_point, float* normal4) {
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        const float* q = xyz + 3 * i;
+        acc[0] += q[0] * q[0]; acc[1] += q[0] * q[1]; acc[2] += q[0] * q[2];
+        acc[3] += q[1] * q[1]; acc[4] += q[1] * q[2]; acc[5] += q[2] * q[2];
+        acc[6] += q[0]; acc[7] += q[1]; acc[8] += q[2];
+    }
+    n_plane_normal(acc, (unsigned)n, view_point, normal4);
+}
+
+}  // extern "C"
