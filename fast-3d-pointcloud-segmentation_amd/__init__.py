@@ -1,0 +1,368 @@
+"""f3ds -- MI355X-native supervoxel + hierarchical-merge segmenter (host-side binding).
+
+Thin ctypes layer over the C-ABI in ``include/f3ds.h`` (``libf3ds.so``, hand-written HIP for
+gfx950).  The classes mirror the reference's interface for this path:
+
+* :class:`Clustering`   -- ``/root/reference/include/supervoxel_clustering/clustering.h:84-212``
+  (same setter names, same exceptions: ``logic_error`` -> :class:`LogicError`,
+  ``invalid_argument`` -> ``ValueError``), fed by :class:`SupervoxelClustering`, the stand-in
+  for ``pcl::SupervoxelClustering<PointXYZRGBA>`` as ``main()`` drives it
+  (``/root/reference/src/supervoxel_clustering.cpp:348-367``).
+* :func:`segment`       -- the whole frame in one call (what ``main()`` does between ``:313``
+  and ``:449``).
+
+There is no CPU fallback: constructing a :class:`Context` without a GPU, or with the shared
+library missing, raises.  PyTorch is not required; device pointers (e.g. ``tensor.data_ptr()``)
+can be passed with ``on_device=True``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libf3ds.so")
+
+NO_LABEL = 0xFFFFFFFF
+LAB_CIEDE00, RGB_EUCL = 0, 1
+NORMALS_DIFF, CONVEX_NORMALS_DIFF = 0, 1
+MANUAL_LAMBDA, ADAPTIVE_LAMBDA, EQUALIZATION = 0, 1, 2
+
+# debug selectors (include/f3ds.h)
+DBG = dict(GRID=0, VOXEL_KEYS=1, VOXEL_COUNT=2, VOXEL_XYZ=3, VOXEL_RGB=4, VOXEL_NORMAL=5, VOXEL_NEIGHBORS=6,
+           POINT_VOXEL=7, SEED_ORIG=8, SEED_KEPT=9, VOXEL_SVLABEL=10, VOXEL_DIST=11, SV_LABELS=12, SV_CENTROID=13,
+           EDGES=14, EDGE_DELTAS=15, EDGE_WEIGHTS=16, MERGES=17, VOXEL_REGION=18, SV_REGION=19)
+DBG_DTYPE = dict(GRID=np.float64, VOXEL_KEYS=np.uint32, VOXEL_COUNT=np.uint32, VOXEL_XYZ=np.float32, VOXEL_RGB=np.float32,
+                 VOXEL_NORMAL=np.float32, VOXEL_NEIGHBORS=np.int32, POINT_VOXEL=np.int32, SEED_ORIG=np.int32, SEED_KEPT=np.int32,
+                 VOXEL_SVLABEL=np.uint32, VOXEL_DIST=np.float32, SV_LABELS=np.uint32, SV_CENTROID=np.float32, EDGES=np.uint32,
+                 EDGE_DELTAS=np.float32, EDGE_WEIGHTS=np.float32, MERGES=np.uint32, VOXEL_REGION=np.uint32, SV_REGION=np.uint32)
+
+
+class F3dsError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("f3ds error %d: %s" % (code, text))
+        self.code = code
+
+
+class LogicError(F3dsError):
+    """std::logic_error of the reference (clustering.cpp:576,591,671)."""
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("voxel_res", ctypes.c_float), ("seed_res", ctypes.c_float), ("w_color", ctypes.c_float),
+                ("w_spatial", ctypes.c_float), ("w_normal", ctypes.c_float), ("use_transform", ctypes.c_int32),
+                ("color_metric", ctypes.c_int32), ("geom_metric", ctypes.c_int32), ("merging", ctypes.c_int32),
+                ("lambda_", ctypes.c_float), ("bins", ctypes.c_int32), ("threshold", ctypes.c_float),
+                ("leaf_order", ctypes.c_int32), ("fold_negative_z", ctypes.c_int32)]
+
+    def copy(self):
+        p = Params()
+        ctypes.memmove(ctypes.byref(p), ctypes.byref(self), ctypes.sizeof(Params))
+        return p
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("n_points", ctypes.c_uint64), ("n_finite", ctypes.c_uint64), ("n_voxels", ctypes.c_uint32),
+                ("octree_depth", ctypes.c_uint32), ("n_seed_cells", ctypes.c_uint32), ("n_seeds", ctypes.c_uint32),
+                ("n_supervoxels", ctypes.c_uint32), ("n_edges", ctypes.c_uint32), ("n_merges", ctypes.c_uint32),
+                ("n_regions", ctypes.c_uint32), ("sweeps", ctypes.c_uint32), ("lambda_", ctypes.c_float),
+                ("ms_total", ctypes.c_float), ("ms_stage", ctypes.c_float * 8)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "ms_stage"}
+        d["ms_stage"] = list(self.ms_stage)
+        return d
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libf3ds.so (built by ``__graft_entry__.build()`` / ``make -C csrc``).  Raises if missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("libf3ds.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()'); "
+                          "this package has no CPU fallback" % p)
+    lib = ctypes.CDLL(p)
+    vp, sz, u32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)
+    lib.f3ds_default_params.argtypes = [ctypes.POINTER(Params)]; lib.f3ds_default_params.restype = None
+    lib.f3ds_version.restype = ctypes.c_int
+    lib.f3ds_strerror.argtypes = [ctypes.c_int]; lib.f3ds_strerror.restype = ctypes.c_char_p
+    lib.f3ds_last_hip_error.restype = ctypes.c_char_p
+    lib.f3ds_device_count.restype = ctypes.c_int
+    lib.f3ds_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_create.restype = ctypes.c_int
+    lib.f3ds_destroy.argtypes = [vp]; lib.f3ds_destroy.restype = None
+    lib.f3ds_set_stream.argtypes = [vp, vp]; lib.f3ds_set_stream.restype = ctypes.c_int
+    lib.f3ds_segment.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.POINTER(Params), vp, ctypes.c_int, ctypes.POINTER(Result)]
+    lib.f3ds_segment.restype = ctypes.c_int
+    lib.f3ds_recluster.argtypes = [vp, ctypes.POINTER(Params), vp, ctypes.c_int, ctypes.POINTER(Result)]
+    lib.f3ds_recluster.restype = ctypes.c_int
+    lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
+    lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
+    lib.f3ds_pcd_read.argtypes = [ctypes.c_char_p, vp, vp, sz, ctypes.POINTER(sz), u32p, u32p]; lib.f3ds_pcd_read.restype = ctypes.c_int
+    lib.f3ds_pcd_write.argtypes = [ctypes.c_char_p, vp, vp, vp, sz, ctypes.c_int]; lib.f3ds_pcd_write.restype = ctypes.c_int
+    lib.f3ds_synth_frame.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp]
+    lib.f3ds_synth_frame.restype = ctypes.c_int
+    lib.f3ds_label_color.argtypes = [ctypes.c_uint32]; lib.f3ds_label_color.restype = ctypes.c_uint32
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc == 0:
+        return
+    text = lib.f3ds_strerror(rc).decode()
+    if rc == -3:
+        text += " [" + lib.f3ds_last_hip_error().decode() + "]"
+    if rc == -5:
+        raise LogicError(rc, text)
+    if rc == -6:
+        raise ValueError(text)
+    raise F3dsError(rc, text)
+
+
+def default_params(**kw):
+    lib = load_library()
+    p = Params()
+    lib.f3ds_default_params(ctypes.byref(p))
+    for k, v in kw.items():
+        if k == "lambda":
+            k = "lambda_"
+        if not hasattr(p, k):
+            raise TypeError("unknown parameter %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def launch_params(**kw):
+    """The reference's canonical flags ``--CVX --AL -t 0.2`` (launch/supervoxel_clustering.launch:3-6)."""
+    d = dict(geom_metric=CONVEX_NORMALS_DIFF, merging=ADAPTIVE_LAMBDA, threshold=0.2)
+    d.update(kw)
+    return default_params(**d)
+
+
+def device_count():
+    return load_library().f3ds_device_count()
+
+
+# ---- host helpers either side of the path -------------------------------------------------------
+def read_pcd(path, with_labels=False):
+    """PCD v0.7 (ascii / binary / binary_compressed) -> (N,4) float32 view of {x,y,z,rgba-bits}."""
+    lib = load_library()
+    n = ctypes.c_size_t(); w = ctypes.c_uint32(); h = ctypes.c_uint32()
+    _check(lib, lib.f3ds_pcd_read(path.encode(), None, None, 0, ctypes.byref(n), ctypes.byref(w), ctypes.byref(h)))
+    pts = np.zeros((n.value, 4), np.float32)
+    labels = np.zeros(n.value, np.uint32) if with_labels else None
+    _check(lib, lib.f3ds_pcd_read(path.encode(), pts.ctypes.data, labels.ctypes.data if with_labels else None, n.value,
+                                  ctypes.byref(n), None, None))
+    return (pts, labels) if with_labels else pts
+
+
+def write_pcd(path, xyz, rgba=None, labels=None, binary=True):
+    lib = load_library()
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    n = len(xyz)
+    rgba = None if rgba is None else np.ascontiguousarray(rgba, np.uint32)
+    labels = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+    _check(lib, lib.f3ds_pcd_write(path.encode(), xyz.ctypes.data, None if rgba is None else rgba.ctypes.data,
+                                   None if labels is None else labels.ctypes.data, n, 1 if binary else 0))
+
+
+def synth_frame(kind, seed, width, height, nan_permille=0):
+    """Deterministic synthetic frame; (N,4) float32, column 3 = rgba bits."""
+    lib = load_library()
+    pts = np.zeros((width * height, 4), np.float32)
+    _check(lib, lib.f3ds_synth_frame(kind, seed, width, height, nan_permille, pts.ctypes.data))
+    return pts
+
+
+def label_color(label):
+    return load_library().f3ds_label_color(label)
+
+
+# ---- device context ------------------------------------------------------------------------------
+class Context:
+    """One (device, stream) pair with its grow-only scratch.  Not thread-safe; one per GPU/stream."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.f3ds_create(device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+        self.result = Result()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.f3ds_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_ptr):
+        _check(self.lib, self.lib.f3ds_set_stream(self.handle, ctypes.c_void_p(hip_stream_ptr)))
+
+    def segment(self, points, params, labels_out=None, n=None, on_device=False):
+        """points: (N,4) float32 ndarray (host) or a device pointer (int) with ``n`` given and
+        ``on_device=True``.  Returns the per-point labels (ndarray) or writes them to the device
+        pointer ``labels_out``."""
+        if on_device:
+            ptr, count = ctypes.c_void_p(int(points)), int(n)
+            out_ptr = ctypes.c_void_p(int(labels_out)) if labels_out is not None else None
+            _check(self.lib, self.lib.f3ds_segment(self.handle, ptr, count, 1, ctypes.byref(params), out_ptr, 1, ctypes.byref(self.result)))
+            return None
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
+        labels = np.empty(len(pts), np.uint32)
+        _check(self.lib, self.lib.f3ds_segment(self.handle, pts.ctypes.data, len(pts), 0, ctypes.byref(params), labels.ctypes.data, 0,
+                                               ctypes.byref(self.result)))
+        self._n = len(pts)
+        return labels
+
+    def recluster(self, params):
+        labels = np.empty(self._n, np.uint32)
+        _check(self.lib, self.lib.f3ds_recluster(self.handle, ctypes.byref(params), labels.ctypes.data, 0, ctypes.byref(self.result)))
+        return labels
+
+    def voxel_cloud(self):
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_voxel_cloud(self.handle, None, None, None, 0, ctypes.byref(n)))
+        xyz = np.zeros((n.value, 3), np.float32); lab = np.zeros(n.value, np.uint32); rgba = np.zeros(n.value, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_voxel_cloud(self.handle, xyz.ctypes.data, lab.ctypes.data, rgba.ctypes.data, n.value, ctypes.byref(n)))
+        return xyz, lab, rgba
+
+    def debug(self, name):
+        nb = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, DBG[name], None, 0, ctypes.byref(nb)))
+        buf = np.zeros(nb.value, np.uint8)
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, DBG[name], buf.ctypes.data, nb.value, ctypes.byref(nb)))
+        return buf.view(DBG_DTYPE[name])
+
+
+def segment(points, params=None, device=0):
+    """XYZRGBA frame -> (per-point region ids, Result).  One-shot convenience wrapper."""
+    ctx = Context(device)
+    try:
+        labels = ctx.segment(points, params or launch_params())
+        res = Result()
+        ctypes.memmove(ctypes.byref(res), ctypes.byref(ctx.result), ctypes.sizeof(Result))
+        return labels, res
+    finally:
+        ctx.close()
+
+
+# ---- mirror of the reference's classes -------------------------------------------------------------
+class SupervoxelClustering:
+    """The nine-call VCCS sequence of main() (supervoxel_clustering.cpp:348-367) as one object."""
+
+    def __init__(self, voxel_resolution, seed_resolution, context=None):
+        self.ctx = context or Context()
+        self.params = default_params(voxel_res=voxel_resolution, seed_res=seed_resolution)
+        self.cloud = None
+
+    def setUseSingleCameraTransform(self, val):
+        self.params.use_transform = 1 if val else 0
+
+    def setInputCloud(self, points):
+        self.cloud = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
+
+    def setColorImportance(self, v):
+        self.params.w_color = v
+
+    def setSpatialImportance(self, v):
+        self.params.w_spatial = v
+
+    def setNormalImportance(self, v):
+        self.params.w_normal = v
+
+
+class Clustering:
+    """Mirror of ``class Clustering`` (clustering.h:84-212) on top of the device path."""
+
+    def __init__(self, c=LAB_CIEDE00, g=NORMALS_DIFF, m=ADAPTIVE_LAMBDA):
+        self.delta_c_type, self.delta_g_type = c, g
+        self.set_merging(m)
+        self._super = None
+        self._labels = None
+
+    def set_delta_c(self, d):
+        self.delta_c_type = d
+
+    def set_delta_g(self, d):
+        self.delta_g_type = d
+
+    def set_merging(self, m):                      # clustering.cpp:562-567
+        self.merging_type, self.lambda_, self.bins_num = m, 0.5, 500
+
+    def set_lambda(self, l):                       # clustering.cpp:574-582
+        if self.merging_type != MANUAL_LAMBDA:
+            raise LogicError(-5, "Lambda can be set only if the merging criterion is set to MANUAL_LAMBDA")
+        if l < 0 or l > 1:
+            raise ValueError("Argument outside range [0, 1]")
+        self.lambda_ = l
+
+    def set_bins_num(self, b):                     # clustering.cpp:589-597
+        if self.merging_type != EQUALIZATION:
+            raise LogicError(-5, "Bins number can be set only if the merging criterion is set to EQUALIZATION")
+        if b < 0:
+            raise ValueError("Argument lower than 0")
+        self.bins_num = b
+
+    def get_delta_c(self):
+        return self.delta_c_type
+
+    def get_delta_g(self):
+        return self.delta_g_type
+
+    def get_merging(self):
+        return self.merging_type
+
+    def get_lambda(self):
+        return self.lambda_
+
+    def get_bins_num(self):
+        return self.bins_num
+
+    def set_initialstate(self, supervoxels):
+        """Takes the SupervoxelClustering object (its extract() result lives on the device)."""
+        self._super = supervoxels
+        self._segmented = False
+
+    def _params(self, threshold):
+        p = self._super.params.copy()
+        p.color_metric, p.geom_metric, p.merging = self.delta_c_type, self.delta_g_type, self.merging_type
+        p.lambda_ = self.lambda_ if self.merging_type == MANUAL_LAMBDA else 0.0
+        p.bins = self.bins_num if self.merging_type == EQUALIZATION else 0
+        p.threshold = threshold
+        return p
+
+    def cluster(self, threshold):                  # clustering.cpp:670-679
+        if self._super is None:
+            raise LogicError(-5, "Cannot call 'cluster' before setting an initial state with 'set_initialstate'")
+        ctx = self._super.ctx
+        if not self._segmented:
+            self._labels = ctx.segment(self._super.cloud, self._params(threshold))
+            self._segmented = True
+        else:
+            self._labels = ctx.recluster(self._params(threshold))
+        if self.merging_type == ADAPTIVE_LAMBDA:
+            self.lambda_ = ctx.result.lambda_
+
+    def get_labeled_cloud(self):                   # clustering.cpp:640-663 -> (xyz, label)
+        xyz, lab, _ = self._super.ctx.voxel_cloud()
+        return xyz, lab
+
+    def get_colored_cloud(self):                   # clustering.cpp:631-633 -> (xyz, rgba)
+        xyz, _, rgba = self._super.ctx.voxel_cloud()
+        return xyz, rgba
+
+    def get_point_labels(self):
+        """Per input point region id (the composition with pcl getLabeledCloud)."""
+        return self._labels

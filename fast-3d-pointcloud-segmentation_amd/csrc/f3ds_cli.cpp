@@ -1,0 +1,177 @@
+// supervoxel_clustering -- drop-in command line for the segmentation path of the reference
+// (/root/reference/src/supervoxel_clustering.cpp:136-476): same flags, defaults, mutual-exclusion
+// rule and exit codes; the VCCS + Clustering work runs in libf3ds (HIP, MI355X) through the C-ABI.
+//
+// Kept from the reference: -d/-p, -v -s -c -z -n, -t, --RGB --CVX --ML --AL --EQ, -r, -f, --NT, --V.
+// Added (additive): -o <pcd> coloured voxel cloud (Clustering::get_colored_cloud), --labels <file>
+// per-point uint32 region ids, --gpu <id>.  Not built yet: the automatic threshold sweep that runs
+// when -t is omitted (needs the Testing evaluator) -- the tool says so and exits 1.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <string>
+#include <vector>
+
+#include "../../include/f3ds.h"
+
+namespace {
+// pcl::console semantics: first exact match; value = atof/atoi of the next token
+int find_argument(int argc, char** argv, const char* name) {
+    for (int i = 1; i < argc; ++i)
+        if (strcmp(argv[i], name) == 0) return i;
+    return -1;
+}
+bool find_switch(int argc, char** argv, const char* name) { return find_argument(argc, argv, name) != -1; }
+void parse(int argc, char** argv, const char* name, float& v) {
+    int i = find_argument(argc, argv, name);
+    if (i > 0 && i + 1 < argc) v = (float)atof(argv[i + 1]);
+}
+void parse(int argc, char** argv, const char* name, int& v) {
+    int i = find_argument(argc, argv, name);
+    if (i > 0 && i + 1 < argc) v = atoi(argv[i + 1]);
+}
+void parse(int argc, char** argv, const char* name, std::string& v) {
+    int i = find_argument(argc, argv, name);
+    if (i > 0 && i + 1 < argc) v = argv[i + 1];
+}
+bool verbose = false;
+#define DEBUG(...) do { if (verbose) fprintf(stderr, __VA_ARGS__); } while (0)
+struct P16 { float x, y, z; uint32_t rgba; };
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        printf("Syntax is: %s {-d <direcory-of-pcd-files> OR -p <pcd-file>} [arguments] \n\n\t"
+               "SUPERVOXEL optional arguments: \n\t"
+               " -v <voxel-resolution>          (default: 0.008) \n\t"
+               " -s <seed-resolution>           (default: 0.08) \n\t"
+               " -c <color-weight>              (default: 0.2) \n\t"
+               " -z <spatial-weight>            (default: 0.4) \n\t"
+               " -n <normal-weight>             (default: 1.0) \n\t\n\t"
+               "SEGMENTATION optional arguments: \n\t"
+               " -t <threshold>                 (default: auto)\n\t"
+               " --RGB                          (RGB euclidean colour distance instead of L*A*B* CIEDE2000) \n\t"
+               " --CVX                          (convexity criterion weighs the geometric distance) \n\t"
+               " --ML [manual-lambda] *         (Manual Lambda merging; lambda=0.5 if no value) \n\t"
+               " --AL                 *         (Adaptive Lambda merging) \n\t"
+               " --EQ [bins-number]   *         (Equalization merging; default bins if no value) \n\t"
+               "  * only one of these can be passed at a time \n\t\n\t"
+               "OTHER optional arguments: \n\t"
+               " -r <label-to-be-removed>       (drops points with this ground-truth label) \n\t"
+               " -f <test-results-filename>     (accepted for compatibility) \n\t"
+               " --NT                           (disables the single camera transform) \n\t"
+               " --V                            (verbose) \n\t"
+               " -o <out.pcd>                   (writes the coloured voxel cloud) \n\t"
+               " --labels <file>                (writes per-point uint32 region ids) \n\t"
+               " --gpu <id>                     (HIP device, default 0) \n",
+               argv[0]);
+        return 1;
+    }
+    verbose = find_switch(argc, argv, "--V");
+    const bool disable_transform = find_switch(argc, argv, "--NT");
+    std::string test_filename = "test";
+    if (find_switch(argc, argv, "-f")) parse(argc, argv, "-f", test_filename);
+    std::string path;
+    std::vector<std::string> file_list;
+    if (find_switch(argc, argv, "-d")) {
+        parse(argc, argv, "-d", path);
+        printf("Counting files in directory...\n");
+        std::error_code ec;
+        if (!std::filesystem::exists(path, ec) || !std::filesystem::is_directory(path, ec)) {
+            fprintf(stderr, "Specified directory doesn't exists or can't be opened\n");
+            return 1;
+        }
+        for (auto it = std::filesystem::recursive_directory_iterator(path, ec); !ec && it != std::filesystem::recursive_directory_iterator(); ++it)
+            if (it->is_regular_file() && it->path().extension() == ".pcd") { file_list.push_back(it->path().string()); DEBUG("File found: %s\n", it->path().c_str()); }
+        printf("Found %zu files\n", file_list.size());
+    } else if (find_switch(argc, argv, "-p")) {
+        parse(argc, argv, "-p", path);
+        file_list.push_back(path);
+    } else {
+        fprintf(stderr, "No input file or directory specified\n");
+        return 1;
+    }
+    const bool thresh_specified = find_switch(argc, argv, "-t");
+    f3ds_params prm;
+    f3ds_default_params(&prm);
+    float thresh = 0;
+    if (thresh_specified) { parse(argc, argv, "-t", thresh); DEBUG("Using threshold: %f\n", thresh); }
+    else DEBUG("Using automatic threshold\n");
+    if (find_switch(argc, argv, "-v")) parse(argc, argv, "-v", prm.voxel_res);
+    if (find_switch(argc, argv, "-s")) parse(argc, argv, "-s", prm.seed_res);
+    if (find_switch(argc, argv, "-c")) parse(argc, argv, "-c", prm.w_color);
+    if (find_switch(argc, argv, "-z")) parse(argc, argv, "-z", prm.w_spatial);
+    if (find_switch(argc, argv, "-n")) parse(argc, argv, "-n", prm.w_normal);
+    const bool rgb = find_switch(argc, argv, "--RGB"), cvx = find_switch(argc, argv, "--CVX");
+    bool ml = find_switch(argc, argv, "--ML"), al = find_switch(argc, argv, "--AL"), eq = find_switch(argc, argv, "--EQ");
+    if (!(ml || al || eq)) { al = true; DEBUG("No merging criterion specified, Adaptive Lambda is going to be used\n"); }
+    else if (!(ml ^ al ^ eq)) { fprintf(stderr, "Only one parameter between --ML --AL and --EQ can be specified at a time\n"); return 1; }
+    float lambda = 0; if (ml) parse(argc, argv, "--ML", lambda);
+    int bin_num = 0; if (eq) parse(argc, argv, "--EQ", bin_num);
+    const bool remove_label = find_switch(argc, argv, "-r");
+    int label_to_be_removed = 0; if (remove_label) parse(argc, argv, "-r", label_to_be_removed);
+    std::string out_pcd, out_labels; int gpu = 0;
+    if (find_switch(argc, argv, "-o")) parse(argc, argv, "-o", out_pcd);
+    if (find_switch(argc, argv, "--labels")) parse(argc, argv, "--labels", out_labels);
+    if (find_switch(argc, argv, "--gpu")) parse(argc, argv, "--gpu", gpu);
+    if (!thresh_specified) {
+        fprintf(stderr, "automatic threshold selection needs the evaluation sweep, which this build does not include yet; pass -t <threshold>\n");
+        return 1;
+    }
+    prm.use_transform = !disable_transform;
+    prm.color_metric = rgb ? F3DS_RGB_EUCL : F3DS_LAB_CIEDE00;
+    prm.geom_metric = cvx ? F3DS_CONVEX_NORMALS_DIFF : F3DS_NORMALS_DIFF;
+    prm.merging = ml ? F3DS_MANUAL_LAMBDA : (eq ? F3DS_EQUALIZATION : F3DS_ADAPTIVE_LAMBDA);
+    prm.lambda = lambda; prm.bins = bin_num; prm.threshold = thresh; prm.fold_negative_z = 1;
+    f3ds_ctx* ctx = nullptr;
+    int rc = f3ds_create(gpu, &ctx);
+    if (rc) { fprintf(stderr, "f3ds_create: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); return 1; }
+    for (const std::string& file : file_list) {
+        printf("Loading pointcloud from PCD file '%s'...\n", file.c_str());
+        size_t n = 0;
+        std::vector<P16> pts; std::vector<uint32_t> gt;
+        if (f3ds_pcd_read(file.c_str(), nullptr, nullptr, 0, &n, nullptr, nullptr) == F3DS_OK) {
+            pts.resize(n); gt.resize(n);
+            if (f3ds_pcd_read(file.c_str(), pts.data(), gt.data(), n, &n, nullptr, nullptr) != F3DS_OK) n = 0;
+        }                                                       // like the reference, a failed load leaves an empty cloud (:313)
+        pts.resize(n); gt.resize(n);
+        if (remove_label) {                                     // :332-336 (has_label is hard-wired true, :309)
+            size_t k = 0;
+            for (size_t i = 0; i < n; ++i) {
+                float z = pts[i].z < 0 ? std::fabs(pts[i].z) : pts[i].z;
+                if (gt[i] != (uint32_t)label_to_be_removed && !(z != z)) { pts[k] = pts[i]; ++k; }
+            }
+            pts.resize(k); n = k;
+        }
+        printf("Pointcloud loaded\nExtracting supervoxels...\n");
+        std::vector<uint32_t> labels(n);
+        f3ds_result res;
+        rc = f3ds_segment(ctx, pts.data(), n, 0, &prm, labels.data(), 0, &res);
+        if (rc) { fprintf(stderr, "f3ds_segment: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
+        printf("Found %u supervoxels\nGetting supervoxel adjacency...\nSegmentation initialization...\n", res.n_supervoxels);
+        if (ml || al) DEBUG("Lambda: %f\n", res.lambda);
+        printf("Initialization complete\nStarting clustering...\nClustering complete\n");
+        printf("%llu points, %u voxels, %u supervoxels, %u adjacencies, %u merges -> %u regions (%.3f ms on GPU %d)\n",
+               (unsigned long long)res.n_points, res.n_voxels, res.n_supervoxels, res.n_edges, res.n_merges, res.n_regions, res.ms_total, gpu);
+        if (!out_pcd.empty() || !out_labels.empty()) {
+            std::string suffix = file_list.size() > 1 ? "." + std::filesystem::path(file).stem().string() : "";
+            if (!out_pcd.empty()) {
+                size_t nv = 0;
+                f3ds_get_voxel_cloud(ctx, nullptr, nullptr, nullptr, 0, &nv);
+                std::vector<float> xyz(nv * 3); std::vector<uint32_t> lab(nv), col(nv);
+                rc = f3ds_get_voxel_cloud(ctx, xyz.data(), lab.data(), col.data(), nv, &nv);
+                if (!rc) rc = f3ds_pcd_write((out_pcd + suffix).c_str(), xyz.data(), col.data(), lab.data(), nv, 1);
+                if (rc) { fprintf(stderr, "writing %s: %s\n", out_pcd.c_str(), f3ds_strerror(rc)); f3ds_destroy(ctx); return 1; }
+            }
+            if (!out_labels.empty()) {
+                FILE* f = fopen((out_labels + suffix).c_str(), "wb");
+                if (!f || fwrite(labels.data(), 4, n, f) != n) { fprintf(stderr, "writing %s failed\n", out_labels.c_str()); if (f) fclose(f); f3ds_destroy(ctx); return 1; }
+                fclose(f);
+            }
+        }
+    }
+    f3ds_destroy(ctx);
+    return 0;
+}
