@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpoints/s segmented end-to-end on synthetic 1M-point RGB-D frames (BASELINE.json).
+
+A *step* is one pass of the whole hot path (voxelise -> normals -> seeds -> sweeps -> adjacency ->
+merge -> per-point labels) over one 1,000,000-point XYZRGBA frame that is already resident in
+HBM when the timed region starts (config 2 of BASELINE.md: 1000x1000 pinhole frame, 3 % NaN,
+flags ``-v 0.008 -s 0.08 --AL --CVX -t 0.2``).  Steps run through ``--streams`` independent
+f3ds contexts (one HIP stream + one host thread each) because a frame contains two latency-bound
+single-workgroup stages (label-propagation sweeps, merge loop) that only fill the chip when
+several frames are in flight; every step still runs the full path on its own frame.
+
+N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU, frames are
+independent so each rank segments its own frames (weak scaling, no data-path collective except
+the label output: one RCCL gather of the uint32 label buffers to rank 0 per step).
+
+The JSON line also carries
+  roofline     -- dominant kernel (by device time, HIP events on the kernel's own stream inside
+                  libf3ds): achieved = 20 B/point x points per launch / mean launch duration,
+                  against the 8 TB/s HBM3E peak;
+  cpu_baseline -- the CPU oracle (single thread, kind "port": the reference needs PCL/OpenCV and
+                  cannot be built here) on one frame of the same workload, rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import queue
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+STAGES = ["voxelise", "neighbours+normals", "seeds", "sweeps", "summaries+adjacency+weights", "merge", "labels"]
+# the kernel that dominates each stage (rocprofv3 --kernel-trace names in profiles/)
+STAGE_KERNEL = {"voxelise": "k_radix_scatter", "neighbours+normals": "k_normals", "seeds": "k_seed_grow", "sweeps": "k_centroid",
+                "summaries+adjacency+weights": "k_lambda", "merge": "k_merge", "labels": "k_point_labels"}
+ALG_BYTES_PER_POINT = 20          # 16 B read of {x,y,z,rgba} + 4 B label write
+HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=8, help="frames in flight per GPU")
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames to cycle through")
+    ap.add_argument("--width", type=int, default=1000)
+    ap.add_argument("--height", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libf3ds has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    P = importlib.import_module("fast-3d-pointcloud-segmentation_amd")
+    prm = P.launch_params(voxel_res=0.008, seed_res=0.08)          # -v 0.008 -s 0.08 --AL --CVX -t 0.2
+    npts = args.width * args.height
+
+    # synthetic frames -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
+    frames_host = [P.synth_frame(0, 1000 + rank * 64 + i, args.width, args.height, 30) for i in range(args.frames)]
+    frames_dev = [torch.from_numpy(f).to(dev) for f in frames_host]
+    nstreams = max(1, args.streams)
+    ctxs = [P.Context(local_rank) for _ in range(nstreams)]
+    label_bufs = [torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(nstreams)]
+    gather_list = [torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+
+    stage_ms = [0.0] * 7
+    stage_lock = threading.Lock()
+    errors = []
+
+    def run_steps(count, record):
+        q = queue.Queue()
+        for s in range(count):
+            q.put(s)
+
+        def worker(w):
+            torch.cuda.set_device(local_rank)
+            ctx = ctxs[w]
+            while True:
+                try:
+                    s = q.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    ctx.segment(frames_dev[s % len(frames_dev)].data_ptr(), prm, labels_out=label_bufs[w].data_ptr(), n=npts, on_device=True)
+                    if world > 1:   # label output of this step: RCCL gather to rank 0 (serialised: one communicator)
+                        with stage_lock:
+                            dist.gather(label_bufs[w], gather_list, dst=0)
+                    if record:
+                        with stage_lock:
+                            for i in range(7):
+                                stage_ms[i] += ctx.result.ms_stage[i]
+                except Exception as e:   # noqa
+                    errors.append(e)
+                    return
+
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(min(nstreams, count))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup, False)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # single-frame latency (one stream, nothing else in flight) for the record
+    barrier()
+    tl = time.perf_counter()
+    for s in range(3):
+        ctxs[0].segment(frames_dev[s % len(frames_dev)].data_ptr(), prm, labels_out=label_bufs[0].data_ptr(), n=npts, on_device=True)
+    latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+    res = ctxs[0].result
+
+    if rank == 0:
+        value = world * args.steps * npts / elapsed / 1e6
+        mean_stage = [m / max(1, args.steps) for m in stage_ms]
+        dom = max(range(7), key=lambda i: mean_stage[i])
+        dom_ms = mean_stage[dom]
+        achieved = ALG_BYTES_PER_POINT * npts / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": STAGE_KERNEL[STAGES[dom]], "stage": STAGES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_POINT * npts,
+                    "whole_frame_achieved_GBps": round(ALG_BYTES_PER_POINT * npts / (sum(mean_stage) * 1e-3) / 1e9, 3) if sum(mean_stage) > 0 else None,
+                    "stage_ms": {STAGES[i]: round(mean_stage[i], 4) for i in range(7)}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from conftest import CpuChecker
+            ora = CpuChecker(os.path.join(ROOT, "oracle", "libf3ds_oracle.so"), "f3ds_oracle")
+            tc = time.perf_counter()
+            rc, olab, ores, oh = ora.segment(frames_host[0], prm)
+            cpu_s = time.perf_counter() - tc
+            assert rc == 0
+            cpu = {"value": round(npts / cpu_s / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+                   "sample": "1 frame (%d points) of the same workload through oracle/libf3ds_oracle.so, %.2f s" % (npts, cpu_s),
+                   "host_cpus": os.cpu_count()}
+            oh.close()
+        line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t 0.2" % (args.width, args.height, npts),
+                           "frames_in_flight_per_gpu": nstreams, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
+                           "label_gather": "RCCL gather to rank 0 per step" if world > 1 else "none",
+                           "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
+                "single_stream_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    for c in ctxs:
+        c.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,9 +145,19 @@ struct SweepView {
 F3DS_HD float a_helper_dist(const SweepView& s, uint32_t g, int v) {
     return n_voxel_distance(s.hc + (size_t)g * 12, s.vf + (size_t)v * 12, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
 }
-#define F3DS_R_STACK 12
-// R(w) for an owned voxel w; *overflow is set when the dependency chain is deeper than the stack
-F3DS_HD bool a_eval_R(const SweepView& s, int w0, int* overflow) {
+#define F3DS_R_STACK 24
+#define F3DS_R_UNKNOWN 0
+#define F3DS_R_TRUE 1
+#define F3DS_R_FALSE 2
+// R(w) for an owned voxel w, memoised in `memo` (one byte per voxel, F3DS_R_UNKNOWN before the
+// sweep).  Concurrent callers may race on memo entries: every writer stores the same value, and a
+// stale "unknown" only costs a recomputation.  *overflow is set when the dependency chain is
+// deeper than the explicit stack.
+F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, int* overflow) {
+    {
+        const unsigned char m0 = memo[w0];
+        if (m0 != F3DS_R_UNKNOWN) return m0 == F3DS_R_TRUE;
+    }
     int node[F3DS_R_STACK];
     int slot[F3DS_R_STACK];
     int sp = 0;
@@ -169,7 +179,10 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w0, int* overflow) {
             if (g == 0u || g >= h) continue;
             if (g != g_cached) { g_cached = g; cached_less = a_helper_dist(s, g, w) < dw; }
             if (!cached_less) continue;
-            // helper g would steal w through u, provided u is still g's at g's turn
+            // helper g steals w through u provided u is still g's at g's turn, i.e. R(u)
+            const unsigned char mu = memo[u];
+            if (mu == F3DS_R_TRUE) { stolen = true; break; }
+            if (mu == F3DS_R_FALSE) continue;
             slot[sp] = k + 1;
             if (sp + 1 >= F3DS_R_STACK) { *overflow = 1; return true; }
             ++sp; node[sp] = u; slot[sp] = 0;
@@ -179,6 +192,7 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w0, int* overflow) {
         if (pushed) continue;
         bool r = !stolen;              // true: nobody steals node[sp] before its owner's turn
         for (;;) {
+            memo[node[sp]] = r ? F3DS_R_TRUE : F3DS_R_FALSE;
             if (sp == 0) return r;
             --sp;
             if (r) { r = false; continue; }   // child still owned -> parent stolen -> R(parent) = false
@@ -199,7 +213,7 @@ F3DS_HD void a_claim(const SweepView& s, const unsigned char* R, int v, uint32_t
             int u = s.nbr[(size_t)v * 27 + k];
             if (u < 0) continue;
             uint32_t gu = s.owner[u];
-            if (gu > last && gu < g && R[u]) g = gu;
+            if (gu > last && gu < g && R[u] == F3DS_R_TRUE) g = gu;
             for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
                 if (gg > last && gg < g) g = gg;
         }

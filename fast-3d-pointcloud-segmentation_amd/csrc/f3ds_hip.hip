@@ -266,7 +266,16 @@ __global__ __launch_bounds__(256) void k_bbox(const P16* pts, uint32_t n, FrameA
         nfin += __shfl_xor(nfin, d, 64);
         any |= __shfl_xor(any, d, 64);
     }
-    if (lane_id() == 0) {
+    __shared__ float smn[4][3], smx[4][3];
+    __shared__ uint32_t sfin[4], sany[4];
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == 0) { for (int a = 0; a < 3; ++a) { smn[w][a] = mn[a]; smx[w][a] = mx[a]; } sfin[w] = nfin; sany[w] = any; }
+    __syncthreads();
+    if (threadIdx.x == 0) {      // one set of atomics per workgroup: ~13 ns each on one address
+        for (int ww = 1; ww < 4; ++ww) {
+            for (int a = 0; a < 3; ++a) { if (smn[ww][a] < mn[a]) mn[a] = smn[ww][a]; if (smx[ww][a] > mx[a]) mx[a] = smx[ww][a]; }
+            nfin += sfin[ww]; any |= sany[ww];
+        }
         if (any) {
             for (int a = 0; a < 3; ++a) { atomicMin(&dc->bbox[a], enc_f32(mn[a])); atomicMax(&dc->bbox[3 + a], enc_f32(mx[a])); }
             atomicOr(&dc->bbox_any, 1u);
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(256) void k_ghost_relink(uint32_t S0, const int* gh
 __global__ __launch_bounds__(256) void k_sweep_R(SweepView s, unsigned char* R, DevCounters* dc) {
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < s.V; v += gridDim.x * blockDim.x) {
         int overflow = 0;
-        R[v] = s.owner[v] ? (unsigned char)a_eval_R(s, v, &overflow) : 0;
+        if (s.owner[v]) a_eval_R(s, v, R, &overflow);
         if (overflow) dc->r_overflow = 1;
     }
 }
@@ -788,18 +797,26 @@ __global__ __launch_bounds__(256) void k_edge_deltas(uint32_t E, const uint32_t*
         }
     }
 }
-// Clustering::deltas_mean over the ascending multisets, then lambda (src/clustering.cpp:267-273)
-__global__ void k_lambda(uint32_t E, const float* deltas, const uint32_t* svals, DevCounters* dc) {
-    const int w = threadIdx.x;
+// Clustering::deltas_mean over the ascending multisets, then lambda (src/clustering.cpp:267-273).
+// The running mean is a serial chain; the 64 lanes fetch the next 64 sorted values of both
+// multisets together and lanes 0 (colour) / 1 (geometry) consume them through readlane.
+__global__ __launch_bounds__(64) void k_lambda(uint32_t E, const float* deltas, const uint32_t* svals, DevCounters* dc) {
+    const int lane = lane_id();
     float count = 0, mean_d = 0;
-    if (w < 2)
-        for (uint32_t i = 0; i < E; ++i) {
-            const float d = deltas[svals[(size_t)w * E + i]];
+    for (uint32_t base = 0; base < E; base += 64u) {
+        const uint32_t i = base + lane;
+        const float vc = i < E ? deltas[svals[i]] : 0.0f;
+        const float vg = i < E ? deltas[svals[(size_t)E + i]] : 0.0f;
+        const int nb = E - base < 64u ? (int)(E - base) : 64;
+        for (int j = 0; j < nb; ++j) {
+            const float dcj = __shfl(vc, j, 64), dgj = __shfl(vg, j, 64);
+            const float d = lane == 0 ? dcj : dgj;
             count++;
             mean_d = mean_d + (1 / count) * (d - mean_d);
         }
+    }
     const float mean_c = __shfl(mean_d, 0, 64), mean_g = __shfl(mean_d, 1, 64);
-    if (w == 0) dc->lambda = mean_g / (mean_c + mean_g);
+    if (lane == 0) dc->lambda = mean_g / (mean_c + mean_g);
 }
 // Clustering::compute_cdf (src/clustering.cpp:289-314) for delta_c (w=0) and delta_g (w=1)
 __global__ __launch_bounds__(256) void k_cdf_hist(uint32_t E, const float* deltas, int bins, uint32_t* hist, DevCounters* dc) {
@@ -843,10 +860,11 @@ __global__ __launch_bounds__(256) void k_edge_weights(MergeDev m, const float* d
     }
 }
 __global__ __launch_bounds__(256) void k_region_reset(uint32_t S0, const uint32_t* hcount, uint32_t* rhead, uint32_t* rtail, uint32_t* lnext, uint32_t* parent,
-                                                     uint32_t* markA, uint32_t* markB) {
+                                                     uint32_t* markA, uint32_t* markB, uint32_t* pool, uint32_t* rstart, uint32_t* rnleaf, uint32_t* rcap) {
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h <= S0; h += gridDim.x * blockDim.x) {
         const bool alive = h > 0 && hcount[h] > 0;
         rhead[h] = alive ? h : 0u; rtail[h] = alive ? h : 0u; lnext[h] = 0u; parent[h] = h; markA[h] = 0u; markB[h] = 0u;
+        pool[h] = h; rstart[h] = h; rnleaf[h] = alive ? 1u : 0u; rcap[h] = 1u;
     }
 }
 
@@ -980,6 +998,240 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge(MergeDev m) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage 5, fast path: the same merge loop with the edge keys and endpoints resident in LDS.
+//   * akey[e]   order key of the edge's weight (0xFFFFFFFF = edge gone); groups of 64 edges keep
+//               their minimum (gkey/gidx), so the next merge is a two-level wave minimum instead of
+//               a scan of all edges; only groups whose edges changed are recomputed.
+//   * eab[e]    endpoints packed a<<16|b: "which edges touch a or b" is a pure LDS scan.
+//   * a region's leaves (original supervoxels, in voxels_ concatenation order) are an array in a
+//     pool, so region b's voxel rows can be gathered by the whole workgroup into an LDS staging
+//     tile (block scan of the leaf lengths + binary search per row); wave 0 then continues a's
+//     nine ordered sums and wave 1 a's running colour mean straight from LDS.
+// Ties between equal keys fall back to the history comparator, exactly like k_merge.
+// ------------------------------------------------------------------------------------------------
+constexpr int ML_THREADS = 512;
+constexpr uint32_t KEY_DEAD = 0xFFFFFFFFu;
+struct MergeLds {
+    uint32_t* pool; uint32_t pool_cap; uint32_t* rstart; uint32_t* rnleaf; uint32_t* rcap;
+    uint32_t Ecap, G, caprows, stage_off, stop_key;
+};
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ inline bool edge_before_k(const MergeDev& m, uint32_t e, uint32_t ke, uint32_t f, uint32_t kf) {
+    EdgeHist H{m.ev_epoch, m.ev_key, m.ev_prev};
+    return a_edge_before(H, e, ke, m.ehist[e], f, kf, m.ehist[f]);
+}
+__global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* akey = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* eab = akey + x.Ecap;
+    uint32_t* gkey = eab + x.Ecap;
+    uint32_t* gidx = gkey + x.G;
+    uint32_t* lstart = gidx + x.G;                 // ML_THREADS + 1
+    uint32_t* lsrc = lstart + ML_THREADS + 1;      // ML_THREADS
+    unsigned char* gdirty = reinterpret_cast<unsigned char*>(lsrc + ML_THREADS);
+    float* stage = reinterpret_cast<float*>(smem + x.stage_off);
+    __shared__ uint32_t s_a, s_b, s_nt, s_nmerges, s_nevents, s_pool_end, s_best;
+    __shared__ int s_stop;
+    __shared__ float s_acc[12];
+    __shared__ float s_rec[16];
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    constexpr int NW = ML_THREADS / 64;
+    MergeParams mp = m.mp;
+    if (mp.merging == 1) mp.lambda = m.dc->lambda;
+    for (uint32_t e = tid; e < x.Ecap; e += ML_THREADS) {
+        akey[e] = e < m.E ? m.eku[e] : KEY_DEAD;
+        eab[e] = e < m.E ? ((m.ea[e] << 16) | m.eb[e]) : 0u;
+    }
+    for (uint32_t g = tid; g < x.G; g += ML_THREADS) gdirty[g] = 1;
+    if (tid == 0) { s_nt = 0; s_nmerges = 0; s_nevents = m.E; s_stop = 0; s_pool_end = m.S0 + 1u; }
+    __syncthreads();
+    for (uint32_t epoch = 1;; ++epoch) {
+        // ---- minima of the groups whose edges changed
+        for (uint32_t g = wave; g < x.G; g += NW) {
+            if (!gdirty[g]) continue;
+            const uint32_t e = g * 64u + lane;
+            const uint32_t k = akey[e];
+            const uint32_t kmin = wave_min_u32(k);
+            uint64_t cand = __ballot(k == kmin);
+            uint32_t idx = g * 64u + (uint32_t)__builtin_ctzll(cand);
+            if (kmin != KEY_DEAD && (cand & (cand - 1ull))) {          // equal keys: weight_map order decides
+                cand &= cand - 1ull;
+                while (cand) { const uint32_t f = g * 64u + (uint32_t)__builtin_ctzll(cand); cand &= cand - 1ull; if (edge_before_k(m, f, kmin, idx, kmin)) idx = f; }
+            }
+            if (lane == 0) { gkey[g] = kmin; gidx[g] = idx; gdirty[g] = 0; }
+        }
+        __syncthreads();
+        // ---- next = *weight_map.begin()
+        if (wave == 0) {
+            uint32_t kloc = KEY_DEAD;
+            for (uint32_t g = lane; g < x.G; g += 64u) { const uint32_t k = gkey[g]; kloc = k < kloc ? k : kloc; }
+            const uint32_t kmin = wave_min_u32(kloc);
+            int stop = !(kmin < x.stop_key);
+            uint32_t best = 0;
+            if (!stop) {
+                uint32_t cnt = 0, first = 0;
+                for (uint32_t g = lane; g < x.G; g += 64u) if (gkey[g] == kmin) { if (!cnt) first = g; cnt++; }
+                const uint64_t has = __ballot(cnt > 0);
+                uint32_t tot = cnt;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                if (tot == 1u) best = gidx[__shfl(first, __builtin_ctzll(has), 64)];
+                else {
+                    bool have = false;
+                    for (uint32_t g = 0; g < x.G; ++g)
+                        if (gkey[g] == kmin) { const uint32_t f = gidx[g]; if (!have || edge_before_k(m, f, kmin, best, kmin)) { best = f; have = true; } }
+                }
+            }
+            if (lane == 0) {
+                s_stop = stop;
+                if (!stop) {
+                    s_best = best;
+                    const uint32_t ab = eab[best];
+                    s_a = ab >> 16; s_b = ab & 0xFFFFu;
+                    const uint32_t k = s_nmerges++;
+                    // weight bits from the order key (weights are never -0 or NaN here)
+                    const uint32_t wb = (kmin & 0x80000000u) ? (kmin & 0x7fffffffu) : ~kmin;
+                    m.merges[k * 3] = s_a; m.merges[k * 3 + 1] = s_b; m.merges[k * 3 + 2] = wb;
+                    akey[best] = KEY_DEAD; gdirty[best >> 6] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (s_stop) break;
+        const uint32_t a = s_a, b = s_b;
+        // ---- edges that touch a or b (LDS scan), leaf array of the merged region
+        for (uint32_t e = tid; e < x.Ecap; e += ML_THREADS) {
+            if (akey[e] == KEY_DEAD) continue;
+            const uint32_t ab = eab[e], p = ab >> 16, q = ab & 0xFFFFu;
+            const bool on_a = p == a || q == a, on_b = p == b || q == b;
+            if (!on_a && !on_b) continue;
+            const uint32_t xx = (p == a || p == b) ? q : p;
+            m.tl[atomicAdd(&s_nt, 1u)] = e;
+            if (on_a) m.markA[xx] = e + 1u; else m.markB[xx] = e + 1u;
+        }
+        // leaf array of a ++ b: append in place while a's segment has room, else move to a segment twice the size
+        const uint32_t a_start = x.rstart[a], na = x.rnleaf[a], cap_a = x.rcap[a], b_start = x.rstart[b], nb = x.rnleaf[b];
+        const bool in_place = na + nb <= cap_a;
+        const uint32_t new_start = in_place ? a_start : s_pool_end;
+        const uint32_t new_cap = in_place ? cap_a : 2u * (na + nb);
+        if (!in_place && new_start + new_cap > x.pool_cap) { if (tid == 0) m.dc->error = F3DS_ERR_UNSUPPORTED; break; }
+        if (in_place) { for (uint32_t i = tid; i < nb; i += ML_THREADS) x.pool[a_start + na + i] = x.pool[b_start + i]; }
+        else { for (uint32_t i = tid; i < na + nb; i += ML_THREADS) x.pool[new_start + i] = i < na ? x.pool[a_start + i] : x.pool[b_start + (i - na)]; }
+        float acc = 0.0f;
+        const uint32_t cnt_a = m.rcnt[a];
+        if (wave == 0 && lane < 9) acc = m.racc[(size_t)a * 12 + lane];
+        if (wave == 1 && lane < 3) acc = m.racc[(size_t)a * 12 + 9 + lane];
+        uint32_t rows_done = 0;
+        bool dedupe_done = false;
+        __syncthreads();
+        const uint32_t nt = s_nt;
+        // ---- voxels_new = voxels_a ++ voxels_b: gather b's rows to LDS, continue a's ordered sums
+        for (uint32_t lc = 0; lc < nb; lc += ML_THREADS) {
+            const uint32_t nl = nb - lc < (uint32_t)ML_THREADS ? nb - lc : (uint32_t)ML_THREADS;
+            uint32_t len = 0, off = 0;
+            if ((uint32_t)tid < nl) { const uint32_t leaf = x.pool[b_start + lc + tid]; len = m.llen[leaf]; off = m.loff[leaf]; }
+            uint32_t T;
+            const uint32_t inc = block_incl_scan<ML_THREADS>(len, &T);
+            lstart[tid] = inc - len; lsrc[tid] = off;
+            if (tid == 0) lstart[ML_THREADS] = T;
+            __syncthreads();
+            for (uint32_t R0 = 0; R0 < T; R0 += x.caprows) {
+                const uint32_t nr = T - R0 < x.caprows ? T - R0 : x.caprows;
+                for (uint32_t r = tid; r < nr; r += ML_THREADS) {
+                    const uint32_t rr = R0 + r;
+                    uint32_t lo = 0, hi = nl;                     // last leaf with lstart <= rr
+                    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (lstart[mid] <= rr) lo = mid; else hi = mid; }
+                    const float4* src = reinterpret_cast<const float4*>(m.rows + (size_t)(lsrc[lo] + (rr - lstart[lo])) * 12);
+                    float4* dst = reinterpret_cast<float4*>(stage + (size_t)r * 12);
+                    const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+                    dst[0] = q0; dst[1] = q1; dst[2] = q2;
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    if (lane < 9) {
+#pragma unroll 8
+                        for (uint32_t j = 0; j < nr; ++j) acc += stage[j * 12 + lane];
+                    }
+                } else if (wave == 1) {
+                    if (lane < 3)
+#pragma unroll 8
+                        for (uint32_t j = 0; j < nr; ++j) {
+                            const float count = (float)(cnt_a + rows_done + j + 1u);
+                            const float inv = 1 / count;
+                            acc = acc + inv * (stage[j * 12 + 9 + lane] - acc);
+                        }
+                } else if (!dedupe_done) {
+                    // contains(): of (a,x) and (b,x) the entry that comes first in the old map survives
+                    for (uint32_t i = tid - 128; i < nt; i += ML_THREADS - 128) {
+                        const uint32_t e = m.tl[i];
+                        const uint32_t ab = eab[e], p = ab >> 16, q = ab & 0xFFFFu;
+                        const bool on_a = p == a || q == a;
+                        const uint32_t xx = (p == a || p == b) ? q : p;
+                        const uint32_t partner = on_a ? m.markB[xx] : m.markA[xx];
+                        if (partner && edge_before_k(m, partner - 1u, akey[partner - 1u], e, akey[e])) m.tl[i] = e | 0x80000000u;
+                    }
+                }
+                dedupe_done = true;
+                rows_done += nr;
+                __syncthreads();
+            }
+        }
+        if (wave == 0 && lane < 9) { s_acc[lane] = acc; m.racc[(size_t)a * 12 + lane] = acc; }
+        if (wave == 1 && lane < 3) { s_acc[9 + lane] = acc; m.racc[(size_t)a * 12 + 9 + lane] = acc; }
+        __syncthreads();
+        if (wave == 0) {
+            float all[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) all[k] = s_acc[k];
+            const uint32_t cnt = cnt_a + rows_done;
+            float rec[16];
+            a_region_from_acc(all, cnt, rec);
+            if (lane == 0) {
+                for (int k = 0; k < 16; ++k) { s_rec[k] = rec[k]; m.rrec[(size_t)a * 16 + k] = rec[k]; }
+                m.rcnt[a] = cnt;
+                x.rstart[a] = new_start; x.rnleaf[a] = na + nb; x.rcap[a] = new_cap; if (!in_place) s_pool_end = new_start + new_cap;
+                m.ralive[b] = 0; m.parent[b] = a;
+            }
+        }
+        __syncthreads();
+        // ---- re-weight the surviving incident edges (delta(), src/clustering.cpp:438-463)
+        for (uint32_t i = tid; i < nt; i += ML_THREADS) {
+            const uint32_t te = m.tl[i], e = te & 0x7fffffffu;
+            const uint32_t ab = eab[e], p = ab >> 16, q = ab & 0xFFFFu;
+            const uint32_t xx = (p == a || p == b) ? q : p;
+            m.markA[xx] = 0u; m.markB[xx] = 0u;
+            gdirty[e >> 6] = 1;
+            if (te & 0x80000000u) { akey[e] = KEY_DEAD; continue; }
+            const uint32_t lo = a < xx ? a : xx, hi = a < xx ? xx : a;
+            float rx[16];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) rx[k] = m.rrec[(size_t)xx * 16 + k];
+            float ra[16];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) ra[k] = s_rec[k];
+            int err = 0;
+            const float w = a < xx ? a_edge_weight(mp, ra, rx, &err) : a_edge_weight(mp, rx, ra, &err);
+            if (err) m.dc->error = err;
+            const uint32_t ev = atomicAdd(&s_nevents, 1u);
+            if (ev >= m.ev_cap) { m.dc->error = F3DS_ERR_UNSUPPORTED; continue; }
+            const uint32_t ku = n_weight_key(w);
+            m.ev_epoch[ev] = epoch; m.ev_key[ev] = ku; m.ev_prev[ev] = m.ehist[e];
+            m.ehist[e] = (int)ev;
+            akey[e] = ku; eab[e] = (lo << 16) | hi;
+        }
+        if (tid == 0) s_nt = 0;
+        __syncthreads();
+        if (m.dc->error) break;
+    }
+    __syncthreads();
+    if (tid == 0) { m.dc->n_merges = s_nmerges; m.dc->n_events = s_nevents; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage 6: region ids and per-point labels
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_roots(uint32_t S0, const uint32_t* parent, const unsigned char* ralive, uint32_t* root, uint32_t* flags) {
@@ -1029,7 +1281,8 @@ struct f3ds_ctx {
     Buf owner0, owner1, dist0, dist1, R, hc, hcount, hlo, hhi, ghost_vox, ghost_active, ghost_done, ghost_head, ghost_next;
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
-    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, rincl;
+    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
+    bool merge_in_lds = false;
 };
 
 namespace {
@@ -1144,7 +1397,23 @@ int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int
         HIPCHECK(hipMemcpyAsync(m.ea, c->ea0.p, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
         HIPCHECK(hipMemcpyAsync(m.eb, c->eb0.p, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
     }
-    hipLaunchKernelGGL(k_region_reset, dim3(grid_for(S0 + 1, 256)), dim3(256), 0, st, S0, (const uint32_t*)c->hcount.p, m.rhead, m.rtail, m.lnext, m.parent, m.markA, m.markB);
+    // fast path: keys + endpoints of every edge and a row staging tile fit the 160 KB LDS of one CU
+    MergeLds xl;
+    memset(&xl, 0, sizeof xl);
+    xl.Ecap = (E + 63u) & ~63u; xl.G = xl.Ecap / 64u;
+    const uint32_t lds_fixed = xl.Ecap * 8u + xl.G * 8u + (2u * ML_THREADS + 1u) * 4u + ((xl.G + 15u) & ~15u);
+    xl.stage_off = (lds_fixed + 15u) & ~15u;
+    const uint32_t lds_budget = 160u * 1024u - 4096u;
+    bool use_lds = E > 0 && S0 <= 65535u && xl.stage_off + 128u * 48u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
+    if (use_lds) { xl.caprows = (lds_budget - xl.stage_off) / 48u; if (xl.caprows > 2048u) xl.caprows = 2048u; }
+    uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
+    xl.pool_cap = (S0 + 1u) * (4u * logS + 8u);
+    ENSURE(c->pool, uint32_t, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
+    ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
+    xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);
+    c->merge_in_lds = use_lds;
+    hipLaunchKernelGGL(k_region_reset, dim3(grid_for(S0 + 1, 256)), dim3(256), 0, st, S0, (const uint32_t*)c->hcount.p, m.rhead, m.rtail, m.lnext, m.parent, m.markA, m.markB,
+                       xl.pool, xl.rstart, xl.rnleaf, xl.rcap);
     float* cdf = nullptr;
     m.mp.color_metric = prm->color_metric; m.mp.geom_metric = prm->geom_metric; m.mp.merging = prm->merging; m.mp.lambda = lambda; m.mp.bins = bins;
     if (E) {
@@ -1171,7 +1440,13 @@ int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int
         hipLaunchKernelGGL(k_edge_weights, dim3(grid_for(E, 256)), dim3(256), 0, st, m, (const float*)deltas);
     }
     HIPCHECK(hipEventRecord(c->ev[5], st));
-    hipLaunchKernelGGL(k_merge, dim3(1), dim3(MG_THREADS), 0, st, m);
+    if (use_lds) {
+        const uint32_t dyn = xl.stage_off + xl.caprows * 48u;
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(k_merge_lds, dim3(1), dim3(ML_THREADS), dyn, st, m, xl);
+    } else {
+        hipLaunchKernelGGL(k_merge, dim3(1), dim3(MG_THREADS), 0, st, m);
+    }
     HIPCHECK(hipEventRecord(c->ev[6], st));
     uint32_t *root, *rflags, *rincl, *d_labels;
     ENSURE(c->root, uint32_t, S0 + 1, root); ENSURE(c->rflags, uint32_t, S0 + 1, rflags); ENSURE(c->rincl, uint32_t, S0 + 1, rincl);
@@ -1284,7 +1559,7 @@ int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_devic
         *c->h_dc = init;
         HIPCHECK(hipMemcpyAsync(c->d_dc, c->h_dc, sizeof init, hipMemcpyHostToDevice, st));
     }
-    if (n) hipLaunchKernelGGL(k_bbox, dim3(grid_for(n, 256)), dim3(256), 0, st, d_pts, n, fa, c->d_dc);
+    if (n) hipLaunchKernelGGL(k_bbox, dim3(grid_for(n, 256 * 8) < 512 ? grid_for(n, 256 * 8) : 512), dim3(256), 0, st, d_pts, n, fa, c->d_dc);
     hipLaunchKernelGGL(k_grid, dim3(1), dim3(1), 0, st, c->d_dc, prm->voxel_res, c->d_grid);
     HIPCHECK(hipMemcpyAsync(c->h_grid, c->d_grid, sizeof(GridInfo), hipMemcpyDeviceToHost, st));
     { int rc = sync_counters(c); if (rc) return rc; }
@@ -1387,6 +1662,7 @@ int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_devic
         for (uint32_t t = 0; t < sweeps; ++t) {
             hipLaunchKernelGGL(k_ghost_relink, dim3(1), dim3(256), 0, st, S0, (const int*)ghost_vox, (const unsigned char*)ghost_active, ghost_head, ghost_next);
             SweepView sv{(int)V, nbr, vf, owner0, dist0, hc, ghost_head, ghost_next, prm->seed_res, prm->w_normal, prm->w_color, prm->w_spatial};
+            HIPCHECK(hipMemsetAsync(R, 0, V, st));
             hipLaunchKernelGGL(k_sweep_R, dim3(grid_for(V, 256)), dim3(256), 0, st, sv, R, c->d_dc);
             hipLaunchKernelGGL(k_sweep_claim, dim3(grid_for(V, 256)), dim3(256), 0, st, sv, (const unsigned char*)R, owner1, dist1, ghost_done, hlo, hhi);
             std::swap(owner0, owner1); std::swap(dist0, dist1);
@@ -1478,16 +1754,20 @@ extern "C" int f3ds_get_voxel_cloud(f3ds_ctx* c, float* xyz, uint32_t* label, ui
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     const uint32_t S0 = c->S0;
-    std::vector<unsigned char> ralive; std::vector<uint32_t> rhead, lnext, loff, llen; std::vector<float> rows;
+    std::vector<unsigned char> ralive; std::vector<uint32_t> rhead, lnext, loff, llen, pool, rstart, rnleaf; std::vector<float> rows;
     int rc;
     if ((rc = fetch(c, c->ralive, S0 + 1, ralive)) || (rc = fetch(c, c->rhead, S0 + 1, rhead)) || (rc = fetch(c, c->lnext, S0 + 1, lnext)) ||
         (rc = fetch(c, c->loff, S0 + 2, loff)) || (rc = fetch(c, c->hcount, S0 + 1, llen)))
         return rc;
+    if (c->merge_in_lds && ((rc = fetch(c, c->pool, c->pool.cap / 4, pool)) || (rc = fetch(c, c->rstart, S0 + 1, rstart)) || (rc = fetch(c, c->rnleaf, S0 + 1, rnleaf)))) return rc;
     if ((rc = fetch(c, c->rows, (size_t)loff[S0 + 1] * 12, rows))) return rc;
     size_t k = 0; uint32_t cur = 0;
     for (uint32_t h = 1; h <= S0; ++h) {
         if (!ralive[h]) continue;
-        for (uint32_t leaf = rhead[h]; leaf; leaf = lnext[leaf])
+        std::vector<uint32_t> leaves;      // the region's leaves in voxels_ concatenation order
+        if (c->merge_in_lds) leaves.assign(pool.begin() + rstart[h], pool.begin() + rstart[h] + rnleaf[h]);
+        else for (uint32_t leaf = rhead[h]; leaf; leaf = lnext[leaf]) leaves.push_back(leaf);
+        for (uint32_t leaf : leaves)
             for (uint32_t j = 0; j < llen[leaf]; ++j) {
                 if (k < cap) {
                     const float* r = &rows[(size_t)(loff[leaf] + j) * 12];

@@ -52,6 +52,27 @@ F3DS_HD bool m_isfinitef(float x) { return (m_bitsf(x) & 0x7f800000u) != 0x7f800
 // 2^k as a double for -1022 <= k <= 1023
 F3DS_HD double m_pow2(int k) { return m_from_bits((uint64_t)(k + 1023) << 52); }
 
+
+// Polynomials are evaluated with Estrin's scheme (independent sub-sums combined with z^2, z^4,
+// z^8) rather than Horner's: on the GPU a dependent f64 operation costs ~14-16 cycles while an
+// independent one issues every 4, and these functions sit on the serial path of the merge loop.
+// The evaluation order below is part of the bit-exact host/device contract.
+F3DS_HD double m_estrin8(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double z) {
+    const double z2 = z * z, z4 = z2 * z2;
+    const double a0 = c0 + c1 * z, a1 = c2 + c3 * z, a2 = c4 + c5 * z, a3 = c6 + c7 * z;
+    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2;
+    return b0 + b1 * z4;
+}
+F3DS_HD double m_estrin16(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double c8, double c9,
+                          double c10, double c11, double c12, double c13, double c14, double c15, double z) {
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double a0 = c0 + c1 * z, a1 = c2 + c3 * z, a2 = c4 + c5 * z, a3 = c6 + c7 * z;
+    const double a4 = c8 + c9 * z, a5 = c10 + c11 * z, a6 = c12 + c13 * z, a7 = c14 + c15 * z;
+    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2, b2 = a4 + a5 * z2, b3 = a6 + a7 * z2;
+    const double d0 = b0 + b1 * z4, d1 = b2 + b3 * z4;
+    return d0 + d1 * z8;
+}
+
 // ---- exp -------------------------------------------------------------------------------
 F3DS_HD double m_exp(double x) {
     if (m_isnan(x)) return x;
@@ -64,22 +85,10 @@ F3DS_HD double m_exp(double x) {
     int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
     double kd = (double)k;
     double r = (x - kd * LN2_HI) - kd * LN2_LO;    // |r| <= ~0.3466
-    // Taylor series, degree 14 (r^15/15! < 1e-19)
-    double p = 1.0 / 87178291200.0;
-    p = p * r + 1.0 / 6227020800.0;
-    p = p * r + 1.0 / 479001600.0;
-    p = p * r + 1.0 / 39916800.0;
-    p = p * r + 1.0 / 3628800.0;
-    p = p * r + 1.0 / 362880.0;
-    p = p * r + 1.0 / 40320.0;
-    p = p * r + 1.0 / 5040.0;
-    p = p * r + 1.0 / 720.0;
-    p = p * r + 1.0 / 120.0;
-    p = p * r + 1.0 / 24.0;
-    p = p * r + 1.0 / 6.0;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    // Taylor series, degree 15 (r^16/16! < 1e-20)
+    const double p = m_estrin16(1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
+                                1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+                                1.0 / 1307674368000.0, r);
     if (k > 1000) return (p * m_pow2(1000)) * m_pow2(k - 1000);
     if (k < -1000) return (p * m_pow2(-1000)) * m_pow2(k + 1000);
     return p * m_pow2(k);
@@ -100,20 +109,9 @@ F3DS_HD double m_log(double x) {
     double f = m - 1.0;
     double s = f / (2.0 + f);
     double z = s * s;
-    // 2*atanh(s) = 2s * (1 + z/3 + z^2/5 + ...),  z <= 0.0295
-    double p = 1.0 / 27.0;
-    p = p * z + 1.0 / 25.0;
-    p = p * z + 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z + 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z + 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z + 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z + 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z + 1.0 / 3.0;
+    // 2*atanh(s) = 2s * (1 + z/3 + z^2/5 + ...),  z <= 0.0295: 16 terms of 1/(2k+3)
+    const double p = m_estrin16(1.0 / 3.0, 1.0 / 5.0, 1.0 / 7.0, 1.0 / 9.0, 1.0 / 11.0, 1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0,
+                                1.0 / 23.0, 1.0 / 25.0, 1.0 / 27.0, 1.0 / 29.0, 1.0 / 31.0, 1.0 / 33.0, z);
     const double LN2_HI = 0x1.62e4200000000p-1;
     const double LN2_LO = 0x1.fdf473de6af28p-22;
     double ed = (double)e;
@@ -128,29 +126,15 @@ F3DS_HD double m_log(double x) {
 // Cody-Waite reduction by pi/2 in three pieces; exact enough for |x| < ~1e5, which covers
 // every argument of the path (hue angles in [0, 4*pi], theta in [0, pi/3]).
 F3DS_HD double m_sin_kernel(double r) {
-    double z = r * r;
-    double p = 1.0 / 355687428096000.0;              // 1/17!
-    p = p * z - 1.0 / 1307674368000.0;               // 1/15!
-    p = p * z + 1.0 / 6227020800.0;                  // 1/13!
-    p = p * z - 1.0 / 39916800.0;                    // 1/11!
-    p = p * z + 1.0 / 362880.0;                      // 1/9!
-    p = p * z - 1.0 / 5040.0;                        // 1/7!
-    p = p * z + 1.0 / 120.0;                         // 1/5!
-    p = p * z - 1.0 / 6.0;                           // 1/3!
+    const double z = r * r;
+    const double p = m_estrin8(-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0, 1.0 / 6227020800.0,
+                               -1.0 / 1307674368000.0, 1.0 / 355687428096000.0, z);
     return r + r * (z * p);
 }
 F3DS_HD double m_cos_kernel(double r) {
-    double z = r * r;
-    double p = 1.0 / 6402373705728000.0;             // 1/18!
-    p = -p;
-    p = p * z + 1.0 / 20922789888000.0;              // 1/16!
-    p = p * z - 1.0 / 87178291200.0;                 // 1/14!
-    p = p * z + 1.0 / 479001600.0;                   // 1/12!
-    p = p * z - 1.0 / 3628800.0;                     // 1/10!
-    p = p * z + 1.0 / 40320.0;                       // 1/8!
-    p = p * z - 1.0 / 720.0;                         // 1/6!
-    p = p * z + 1.0 / 24.0;                          // 1/4!
-    p = p * z - 0.5;
+    const double z = r * r;
+    const double p = m_estrin16(-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0, -1.0 / 87178291200.0,
+                                1.0 / 20922789888000.0, -1.0 / 6402373705728000.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, z);
     return 1.0 + z * p;
 }
 F3DS_HD int m_rem_pio2(double x, double* r) {
@@ -195,23 +179,9 @@ F3DS_HD double m_atan01(double t) {
     if (t < 0.25) { hi = 0.0; lo = 0.0; u = t; }
     else if (t < 0.75) { hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56; u = (t - 0.5) / (1.0 + 0.5 * t); }
     else { hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55; u = (t - 1.0) / (1.0 + t); }
-    double z = u * u;                                // <= 0.0625
-    double p = 1.0 / 31.0;
-    p = -p;
-    p = p * z + 1.0 / 29.0;
-    p = p * z - 1.0 / 27.0;
-    p = p * z + 1.0 / 25.0;
-    p = p * z - 1.0 / 23.0;
-    p = p * z + 1.0 / 21.0;
-    p = p * z - 1.0 / 19.0;
-    p = p * z + 1.0 / 17.0;
-    p = p * z - 1.0 / 15.0;
-    p = p * z + 1.0 / 13.0;
-    p = p * z - 1.0 / 11.0;
-    p = p * z + 1.0 / 9.0;
-    p = p * z - 1.0 / 7.0;
-    p = p * z + 1.0 / 5.0;
-    p = p * z - 1.0 / 3.0;
+    const double z = u * u;                          // <= 0.0625
+    const double p = m_estrin16(-1.0 / 3.0, 1.0 / 5.0, -1.0 / 7.0, 1.0 / 9.0, -1.0 / 11.0, 1.0 / 13.0, -1.0 / 15.0, 1.0 / 17.0, -1.0 / 19.0,
+                                1.0 / 21.0, -1.0 / 23.0, 1.0 / 25.0, -1.0 / 27.0, 1.0 / 29.0, -1.0 / 31.0, 1.0 / 33.0, z);
     double a = u + u * (z * p);
     return hi + (a + lo);
 }

@@ -341,7 +341,7 @@ F3DS_HD void n_delta_c_g(const float* r1, const float* r2, int color_metric, int
 // multimap<float,...> order with NaN after every number (the reference's behaviour with NaN
 // keys is undefined); -0 and +0 compare equal like operator<
 F3DS_HD uint32_t n_weight_key(float w) {
-    if (w != w) return 0xFFFFFFFFu;
+    if (w != w) return 0xFFFFFFFEu;      // 0xFFFFFFFF is left free for "no edge"
     uint32_t b = m_bitsf(w);
     if (b == 0x80000000u) b = 0u;
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);

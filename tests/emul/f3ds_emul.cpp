@@ -242,7 +242,8 @@ int stage_sweeps(f3ds_emul& E) {
         SweepView s{V, E.nbr.data(), E.vf.data(), E.owner.data(), E.dist.data(), E.hc.data(), ghost_head.data(), ghost_next.data(),
                     prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
         int overflow = 0;
-        for (int v = 0; v < V; ++v) R[v] = E.owner[v] ? (unsigned char)a_eval_R(s, v, &overflow) : 0;
+        std::fill(R.begin(), R.end(), (unsigned char)F3DS_R_UNKNOWN);
+        for (int v = 0; v < V; ++v) if (E.owner[v]) a_eval_R(s, v, R.data(), &overflow);
         if (overflow) return F3DS_ERR_UNSUPPORTED;
         std::fill(done.begin(), done.end(), 0);
         for (int v = 0; v < V; ++v) a_claim(s, R.data(), v, &owner2[v], &dist2[v], done.data());

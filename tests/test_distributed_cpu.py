@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: two gloo processes shard frames round-robin and gather label buffers to
+rank 0 with the same helper bench.py / a multi-GPU batch driver uses over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, pkg
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_frames, npts, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    B = importlib.import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    mine = B.frames_of_rank(n_frames, rank, world)
+    # stand-in labels: a deterministic function of (frame, point) so rank 0 can verify the routing
+    local = [torch.from_numpy(((np.arange(npts, dtype=np.int64) * 7 + f * 1000003) % 97).astype(np.int32)) for f in mine]
+    got = B.gather_labels(local, dist, dst=0)
+    if rank == 0:
+        ok = sorted(got) == list(range(n_frames))
+        for f, t in got.items():
+            ok &= bool(np.array_equal(t.numpy(), ((np.arange(npts, dtype=np.int64) * 7 + f * 1000003) % 97).astype(np.int32)))
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [4, 5])
+def test_two_rank_shard_and_gather(n_frames):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, 5000, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_round_robin_partition():
+    B = __import__("importlib").import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    for world in (1, 2, 4, 8):
+        seen = sorted(i for r in range(world) for i in B.frames_of_rank(64, r, world))
+        assert seen == list(range(64))
+        assert all(len(B.frames_of_rank(64, r, world)) == 64 // world for r in range(world))

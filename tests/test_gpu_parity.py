@@ -1,37 +1,23 @@
-"""GPU parity proper: libf3ds (HIP, through the C-ABI) against the CPU oracle, bit for bit, on every
-intermediate array the two expose.  Sizes are chosen so the oracle finishes in seconds."""
+"""GPU parity proper: libf3ds (HIP, through the C-ABI) against the CPU oracle and the committed
+golden file, bit for bit, on every intermediate array.  Sizes: the oracle finishes in seconds."""
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import ALL_DEBUG, FIXTURE_PCD, first_mismatch
+from conftest import ALL_DEBUG, ROOT, first_mismatch
+from golden_cases import GOLDEN_CASES, case_params, case_points
 
 pytestmark = pytest.mark.gpu
-
-CASES = {
-    # name: (synth args or 'fixture', param overrides)
-    "rgbd_160x120": ((0, 7, 160, 120, 30), dict(voxel_res=0.02, seed_res=0.2)),
-    "rgbd_320x240_ghosts": ((0, 11, 320, 240, 50), dict(voxel_res=0.012, seed_res=0.1)),
-    "rgbd_160x120_desc_leaf_order": ((0, 7, 160, 120, 30), dict(voxel_res=0.02, seed_res=0.2, leaf_order=1)),
-    "rgbd_160x120_no_transform": ((0, 7, 160, 120, 30), dict(voxel_res=0.02, seed_res=0.2, use_transform=0)),
-    "rgbd_160x120_rgb_metric": ((0, 7, 160, 120, 30), dict(voxel_res=0.02, seed_res=0.2, color_metric=1)),
-    "rgbd_160x120_equalization": ((0, 7, 160, 120, 30), dict(voxel_res=0.02, seed_res=0.2, merging=2)),
-    "rgbd_160x120_manual_lambda": ((0, 7, 160, 120, 30), dict(voxel_res=0.02, seed_res=0.2, merging=0, lambda_=0.3)),
-    "fused_200k_nan_lambda": ((1, 3000, 400, 500, 0), dict(voxel_res=0.04, seed_res=0.4, use_transform=0)),
-    "fixture_launch_flags": ("fixture", {}),
-}
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
 
 
-def _points(P, spec):
-    if spec == "fixture":
-        return P.read_pcd(FIXTURE_PCD)
-    return P.synth_frame(*spec)
-
-
-@pytest.mark.parametrize("name", list(CASES))
-def test_every_stage_matches_oracle(P, oracle, gpu_ctx, name):
-    spec, kw = CASES[name]
-    pts = _points(P, spec)
-    prm = P.launch_params(**kw)
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name):
+    pts = case_points(P, name)
+    prm = case_params(P, name)
     rc, olab, ores, oh = oracle.segment(pts, prm)
     assert rc == 0
     glab = gpu_ctx.segment(pts, prm)
@@ -40,12 +26,109 @@ def test_every_stage_matches_oracle(P, oracle, gpu_ctx, name):
         assert getattr(gres, f) == getattr(ores, f), f
     problems = []
     for what in ALL_DEBUG:
-        m = first_mismatch(what, oh.get(what), gpu_ctx.debug(what))
+        got = gpu_ctx.debug(what)
+        m = first_mismatch(what, oh.get(what), got)
         if m:
             problems.append(m)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == GOLD[name]["sha256"][what] or m, what
     assert not problems, "\n".join(problems)
     assert np.array_equal(olab, glab)
+    assert hashlib.sha256(glab.tobytes()).hexdigest() == GOLD[name]["labels_sha256"]
     assert (np.isnan(ores.lambda_) and np.isnan(gres.lambda_)) or ores.lambda_ == gres.lambda_
     ox, ol, oc = oh.voxel_cloud()
     gx, gl, gc = gpu_ctx.voxel_cloud()
     assert np.array_equal(ox.view(np.uint32), gx.view(np.uint32)) and np.array_equal(ol, gl) and np.array_equal(oc, gc)
+
+
+def test_global_memory_merge_kernel_matches_too(P, oracle, monkeypatch):
+    """k_merge (edges in HBM, used when they do not fit LDS) against the oracle."""
+    monkeypatch.setenv("F3DS_FORCE_GLOBAL_MERGE", "1")
+    ctx = P.Context(0)
+    for name in ("rgbd_320x240_ghosts", "fixture_launch_flags"):
+        pts = case_points(P, name); prm = case_params(P, name)
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        glab = ctx.segment(pts, prm)
+        assert np.array_equal(olab, glab)
+        assert not first_mismatch("MERGES", oh.get("MERGES"), ctx.debug("MERGES"))
+        ox, ol, _ = oh.voxel_cloud(); gx, gl, _ = ctx.voxel_cloud()
+        assert np.array_equal(ox.view(np.uint32), gx.view(np.uint32)) and np.array_equal(ol, gl)
+    ctx.close()
+
+
+def test_recluster_and_clustering_mirror(P, oracle, gpu_ctx):
+    """Clustering::cluster(threshold) again on the same supervoxels, with other metrics."""
+    pts = case_points(P, "rgbd_160x120")
+    sv = P.SupervoxelClustering(0.02, 0.2, context=gpu_ctx)
+    sv.setUseSingleCameraTransform(True); sv.setInputCloud(pts)
+    sv.setColorImportance(0.2); sv.setSpatialImportance(0.4); sv.setNormalImportance(1.0)
+    seg = P.Clustering()
+    seg.set_delta_g(P.CONVEX_NORMALS_DIFF)
+    seg.set_initialstate(sv)
+    seg.cluster(0.2)
+    rc, olab, ores, oh = oracle.segment(pts, case_params(P, "rgbd_160x120"))
+    assert np.array_equal(seg.get_point_labels(), olab) and seg.get_lambda() == ores.lambda_
+    for name in ("rgbd_160x120_rgb_metric", "rgbd_160x120_equalization", "rgbd_160x120_manual_lambda", "rgbd_160x120_threshold_1"):
+        prm = case_params(P, name)
+        seg.set_delta_c(prm.color_metric); seg.set_delta_g(prm.geom_metric); seg.set_merging(prm.merging)
+        if prm.merging == P.MANUAL_LAMBDA and prm.lambda_:
+            seg.set_lambda(prm.lambda_)
+        seg.cluster(prm.threshold)                     # second call: recluster on the device-resident supervoxels
+        rc, ol2, or2, oh2 = oracle.segment(pts, prm)
+        assert np.array_equal(seg.get_point_labels(), ol2), name
+        xyz, lab = seg.get_labeled_cloud()
+        ox, ol, _ = oh2.voxel_cloud()
+        assert np.array_equal(xyz.view(np.uint32), ox.view(np.uint32)) and np.array_equal(lab, ol), name
+
+
+def test_edge_cases(P, oracle, gpu_ctx):
+    prm = P.launch_params(voxel_res=0.02, seed_res=0.2)
+    nan = np.float32("nan")
+    cases = {
+        "empty": np.zeros((0, 4), np.float32),
+        "all_nan": np.full((10, 4), nan, np.float32),
+        "single": np.array([[0.1, 0.2, 1.0, 0]], np.float32),
+        "two_identical": np.array([[0.1, 0.2, 1.0, 0], [0.1, 0.2, 1.0, 0]], np.float32),
+        "z_zero_and_inf": np.array([[0.1, 0.2, 0.0, 0], [0.3, 0.1, 1.0, 0], [0.3, 0.1, np.inf, 0], [0.5, 0.5, 2.0, 0]], np.float32),
+        "negative_z_folded": np.array([[0.1, 0.2, -1.0, 0], [0.1, 0.2, 1.0, 0]], np.float32),
+        "tiny_plane": P.synth_frame(0, 3, 24, 18, 0),
+    }
+    for name, pts in cases.items():
+        rc, olab, ores, _ = oracle.segment(pts, prm)
+        assert rc == 0, name
+        glab = gpu_ctx.segment(pts, prm)
+        assert np.array_equal(olab, glab), name
+        assert gpu_ctx.result.n_voxels == ores.n_voxels and gpu_ctx.result.n_regions == ores.n_regions, name
+    with pytest.raises(P.F3dsError):
+        gpu_ctx.segment(cases["single"], P.launch_params(voxel_res=0.0))
+    with pytest.raises(ValueError):
+        gpu_ctx.segment(cases["tiny_plane"], P.launch_params(voxel_res=0.02, seed_res=0.2, merging=0, lambda_=1.5))
+
+
+def test_device_pointers_and_streams(P, oracle, gpu_ctx):
+    """Caller-owned device buffers (torch tensors) in, labels out on the device, on a torch stream."""
+    torch = pytest.importorskip("torch")
+    pts = case_points(P, "rgbd_160x120"); prm = case_params(P, "rgbd_160x120")
+    d_pts = torch.from_numpy(pts).cuda(); d_lab = torch.empty(len(pts), dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    gpu_ctx.set_stream(st.cuda_stream)
+    gpu_ctx.segment(d_pts.data_ptr(), prm, labels_out=d_lab.data_ptr(), n=len(pts), on_device=True)
+    gpu_ctx.set_stream(0)
+    rc, olab, _, _ = oracle.segment(pts, prm)
+    assert np.array_equal(d_lab.cpu().numpy().view(np.uint32), olab)
+
+
+def test_cli_on_fixture(P, oracle, tmp_path):
+    import subprocess
+    from conftest import FIXTURE_PCD
+    exe = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd", "supervoxel_clustering")
+    out = str(tmp_path / "seg.pcd"); lab = str(tmp_path / "labels.u32")
+    r = subprocess.run([exe, "--CVX", "--AL", "-t", "0.2", "-p", FIXTURE_PCD, "-o", out, "--labels", lab], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Found 597 supervoxels" in r.stdout
+    pts = P.read_pcd(FIXTURE_PCD)
+    rc, olab, ores, oh = oracle.segment(pts, P.launch_params())
+    assert np.array_equal(np.fromfile(lab, np.uint32), olab)
+    cloud, clab = P.read_pcd(out, with_labels=True)
+    ox, ol, oc = oh.voxel_cloud()
+    assert np.array_equal(cloud[:, :3].view(np.uint32), ox.view(np.uint32)) and np.array_equal(clab, ol)
+    assert np.array_equal(cloud[:, 3].copy().view(np.uint32), oc)
