@@ -1015,10 +1015,19 @@ struct MergeLds {
     uint32_t* pool; uint32_t pool_cap; uint32_t* rstart; uint32_t* rnleaf; uint32_t* rcap;
     uint32_t Ecap, G, caprows, stage_off, stop_key;
 };
+// wave-wide unsigned minimum with DPP lane swizzles (quad, half-row, row, row broadcasts): six VALU
+// steps instead of six ds_bpermute round trips; every lane returns the result.
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
-    return v;
+#define F3DS_DPP_MIN(ctrl, rmask)                                                                          \
+    { const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false); v = t_ < v ? t_ : v; }
+    F3DS_DPP_MIN(0xB1, 0xF)     // quad_perm [1,0,3,2]
+    F3DS_DPP_MIN(0x4E, 0xF)     // quad_perm [2,3,0,1]
+    F3DS_DPP_MIN(0x141, 0xF)    // row_half_mirror
+    F3DS_DPP_MIN(0x140, 0xF)    // row_mirror: every lane of a row holds the row minimum
+    F3DS_DPP_MIN(0x142, 0xA)    // row_bcast15 into rows 1 and 3
+    F3DS_DPP_MIN(0x143, 0xC)    // row_bcast31 into rows 2 and 3
+#undef F3DS_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ inline bool edge_before_k(const MergeDev& m, uint32_t e, uint32_t ke, uint32_t f, uint32_t kf) {
     EdgeHist H{m.ev_epoch, m.ev_key, m.ev_prev};
@@ -1034,6 +1043,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
     uint32_t* lsrc = lstart + ML_THREADS + 1;      // ML_THREADS
     unsigned char* gdirty = reinterpret_cast<unsigned char*>(lsrc + ML_THREADS);
     float* stage = reinterpret_cast<float*>(smem + x.stage_off);
+    float* sinv = stage + (size_t)x.caprows * 12;   // 1/count of every staged row (the colour running mean)
     __shared__ uint32_t s_a, s_b, s_nt, s_nmerges, s_nevents, s_pool_end, s_best;
     __shared__ int s_stop;
     __shared__ float s_acc[12];
@@ -1149,6 +1159,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
                     float4* dst = reinterpret_cast<float4*>(stage + (size_t)r * 12);
                     const float4 q0 = src[0], q1 = src[1], q2 = src[2];
                     dst[0] = q0; dst[1] = q1; dst[2] = q2;
+                    const float count = (float)(cnt_a + rows_done + r + 1u);
+                    sinv[r] = 1 / count;
                 }
                 __syncthreads();
                 if (wave == 0) {
@@ -1159,11 +1171,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
                 } else if (wave == 1) {
                     if (lane < 3)
 #pragma unroll 8
-                        for (uint32_t j = 0; j < nr; ++j) {
-                            const float count = (float)(cnt_a + rows_done + j + 1u);
-                            const float inv = 1 / count;
-                            acc = acc + inv * (stage[j * 12 + 9 + lane] - acc);
-                        }
+                        for (uint32_t j = 0; j < nr; ++j) acc = acc + sinv[j] * (stage[j * 12 + 9 + lane] - acc);
                 } else if (!dedupe_done) {
                     // contains(): of (a,x) and (b,x) the entry that comes first in the old map survives
                     for (uint32_t i = tid - 128; i < nt; i += ML_THREADS - 128) {
@@ -1183,18 +1191,38 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
         if (wave == 0 && lane < 9) { s_acc[lane] = acc; m.racc[(size_t)a * 12 + lane] = acc; }
         if (wave == 1 && lane < 3) { s_acc[9 + lane] = acc; m.racc[(size_t)a * 12 + 9 + lane] = acc; }
         __syncthreads();
+        // ---- the merged region's record: wave 0 centroid + PCA normal, wave 1 mean colour -> Lab
         if (wave == 0) {
-            float all[12];
+            float all[9];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) all[k] = s_acc[k];
+            for (int k = 0; k < 9; ++k) all[k] = s_acc[k];
             const uint32_t cnt = cnt_a + rows_done;
-            float rec[16];
-            a_region_from_acc(all, cnt, rec);
+            const float c = (float)cnt;
+            const float cen[3] = {all[6] / c, all[7] / c, all[8] / c};
+            float n4[4];
+            n_plane_normal(all, cnt, cen, n4);
             if (lane == 0) {
-                for (int k = 0; k < 16; ++k) { s_rec[k] = rec[k]; m.rrec[(size_t)a * 16 + k] = rec[k]; }
+                for (int k = 0; k < 3; ++k) { s_rec[k] = cen[k]; s_rec[3 + k] = n4[k]; m.rrec[(size_t)a * 16 + k] = cen[k]; m.rrec[(size_t)a * 16 + 3 + k] = n4[k]; }
                 m.rcnt[a] = cnt;
                 x.rstart[a] = new_start; x.rnleaf[a] = na + nb; x.rcap[a] = new_cap; if (!in_place) s_pool_end = new_start + new_cap;
                 m.ralive[b] = 0; m.parent[b] = a;
+            }
+        } else if (wave == 1) {
+            // n_rgb2lab with the three gamma curves and the three cube roots evaluated in lanes 0..2
+            const float mr = s_acc[9], mg = s_acc[10], mb = s_acc[11];
+            const float mine = lane == 0 ? mr : (lane == 1 ? mg : mb);
+            const float v = mine / 255;
+            const float cl = v <= 0.04045f ? v / 12.92f : (float)m_pow_pos((double)((v + 0.055f) / 1.055f), 2.4);
+            const float c0 = __shfl(cl, 0, 64), c1 = __shfl(cl, 1, 64), c2 = __shfl(cl, 2, 64);
+            const float X = (c0 * 0.412453f + c1 * 0.357580f + c2 * 0.180423f) / 0.950456f;
+            const float Y = (c0 * 0.212671f + c1 * 0.715160f + c2 * 0.072169f);
+            const float Z = (c0 * 0.019334f + c1 * 0.119193f + c2 * 0.950227f) / 1.088754f;
+            const float fl = n_lab_f(lane == 0 ? X : (lane == 1 ? Y : Z));
+            const float fx = __shfl(fl, 0, 64), fy = __shfl(fl, 1, 64), fz = __shfl(fl, 2, 64);
+            const float L = Y > 0.008856f ? 116.0f * fy - 16.0f : 903.3f * Y;
+            if (lane == 0) {
+                const float rec[6] = {mr, mg, mb, L, 500.0f * (fx - fy), 200.0f * (fy - fz)};
+                for (int k = 0; k < 6; ++k) { s_rec[6 + k] = rec[k]; m.rrec[(size_t)a * 16 + 6 + k] = rec[k]; }
             }
         }
         __syncthreads();
@@ -1207,14 +1235,17 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
             gdirty[e >> 6] = 1;
             if (te & 0x80000000u) { akey[e] = KEY_DEAD; continue; }
             const uint32_t lo = a < xx ? a : xx, hi = a < xx ? xx : a;
-            float rx[16];
+            float r1[12], r2[12];          // record of the lower label first, like delta(segments.at(first), segments.at(second))
+            {
+                const float4* gx = reinterpret_cast<const float4*>(m.rrec + (size_t)xx * 16);
+                const float4 x0 = gx[0], x1 = gx[1], x2 = gx[2];
+                const float rx[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+                const bool a_first = a < xx;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) rx[k] = m.rrec[(size_t)xx * 16 + k];
-            float ra[16];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) ra[k] = s_rec[k];
+                for (int k = 0; k < 12; ++k) { const float ra = s_rec[k]; r1[k] = a_first ? ra : rx[k]; r2[k] = a_first ? rx[k] : ra; }
+            }
             int err = 0;
-            const float w = a < xx ? a_edge_weight(mp, ra, rx, &err) : a_edge_weight(mp, rx, ra, &err);
+            const float w = a_edge_weight(mp, r1, r2, &err);
             if (err) m.dc->error = err;
             const uint32_t ev = atomicAdd(&s_nevents, 1u);
             if (ev >= m.ev_cap) { m.dc->error = F3DS_ERR_UNSUPPORTED; continue; }
@@ -1404,8 +1435,8 @@ int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int
     const uint32_t lds_fixed = xl.Ecap * 8u + xl.G * 8u + (2u * ML_THREADS + 1u) * 4u + ((xl.G + 15u) & ~15u);
     xl.stage_off = (lds_fixed + 15u) & ~15u;
     const uint32_t lds_budget = 160u * 1024u - 4096u;
-    bool use_lds = E > 0 && S0 <= 65535u && xl.stage_off + 128u * 48u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
-    if (use_lds) { xl.caprows = (lds_budget - xl.stage_off) / 48u; if (xl.caprows > 2048u) xl.caprows = 2048u; }
+    bool use_lds = E > 0 && S0 <= 65535u && xl.stage_off + 128u * 52u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
+    if (use_lds) { xl.caprows = (lds_budget - xl.stage_off) / 52u; if (xl.caprows > 2048u) xl.caprows = 2048u; }
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u);
     ENSURE(c->pool, uint32_t, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
@@ -1441,7 +1472,7 @@ int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int
     }
     HIPCHECK(hipEventRecord(c->ev[5], st));
     if (use_lds) {
-        const uint32_t dyn = xl.stage_off + xl.caprows * 48u;
+        const uint32_t dyn = xl.stage_off + xl.caprows * 52u;
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(k_merge_lds, dim3(1), dim3(ML_THREADS), dyn, st, m, xl);
     } else {

@@ -7,6 +7,11 @@ import sys
 import numpy as np
 import pytest
 
+try:                      # torch bundles its own HIP runtime: when both live in one process torch must load first,
+    import torch  # noqa   # libf3ds then binds to the runtime that is already mapped
+except ImportError:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
