@@ -50,9 +50,10 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--streams", type=int, default=16, help="frames in flight per GPU")
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--batch", type=int, default=16, help="frames per f3ds_segment_batch call")
+    ap.add_argument("--groups", type=int, default=3, help="batch calls in flight per GPU")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames to cycle through")
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--height", type=int, default=1000)
@@ -81,9 +82,13 @@ def main():
     # synthetic frames -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
     frames_host = [P.synth_frame(0, 1000 + rank * 64 + i, args.width, args.height, 30) for i in range(args.frames)]
     frames_dev = [torch.from_numpy(f).to(dev) for f in frames_host]
-    nstreams = max(1, args.streams)
-    ctxs = [P.Context(local_rank) for _ in range(nstreams)]
-    label_bufs = [torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(nstreams)]
+    # frames in flight = groups x batch: every group segments `batch` frames per f3ds_segment_batch call
+    # (wide stages on one stream per frame, all merge loops of the batch in ONE dispatch); `groups` such
+    # calls run concurrently from host threads so one batch's wide stages overlap another's merge loops.
+    nbatch, ngroups = max(1, args.batch), max(1, args.groups)
+    nstreams = nbatch * ngroups
+    ctxs = [[P.Context(local_rank) for _ in range(nbatch)] for _ in range(ngroups)]
+    label_bufs = [[torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(nbatch)] for _ in range(ngroups)]
     gather_list = [torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
@@ -93,31 +98,34 @@ def main():
 
     def run_steps(count, record):
         q = queue.Queue()
-        for s in range(count):
-            q.put(s)
+        for s0 in range(0, count, nbatch):
+            q.put(list(range(s0, min(count, s0 + nbatch))))
 
-        def worker(w):
+        def worker(g):
             torch.cuda.set_device(local_rank)
-            ctx = ctxs[w]
             while True:
                 try:
-                    s = q.get_nowait()
+                    steps = q.get_nowait()
                 except queue.Empty:
                     return
                 try:
-                    ctx.segment(frames_dev[s % len(frames_dev)].data_ptr(), prm, labels_out=label_bufs[w].data_ptr(), n=npts, on_device=True)
-                    if world > 1:   # label output of this step: RCCL gather to rank 0 (serialised: one communicator)
+                    k = len(steps)
+                    P.segment_batch(ctxs[g][:k], [frames_dev[s % len(frames_dev)].data_ptr() for s in steps], prm,
+                                    labels_out=[label_bufs[g][i].data_ptr() for i in range(k)], n=[npts] * k, on_device=True)
+                    if world > 1:   # label output of these steps: one RCCL gather to rank 0 per frame
                         with stage_lock:
-                            dist.gather(label_bufs[w], gather_list, dst=0)
+                            for i in range(k):
+                                dist.gather(label_bufs[g][i], gather_list, dst=0)
                     if record:
                         with stage_lock:
-                            for i in range(7):
-                                stage_ms[i] += ctx.result.ms_stage[i]
+                            for i in range(k):
+                                for j in range(7):
+                                    stage_ms[j] += ctxs[g][i].result.ms_stage[j]
                 except Exception as e:   # noqa
                     errors.append(e)
                     return
 
-        threads = [threading.Thread(target=worker, args=(w,)) for w in range(min(nstreams, count))]
+        threads = [threading.Thread(target=worker, args=(g,)) for g in range(ngroups)]
         for t in threads:
             t.start()
         for t in threads:
@@ -145,9 +153,9 @@ def main():
     barrier()
     tl = time.perf_counter()
     for s in range(3):
-        ctxs[0].segment(frames_dev[s % len(frames_dev)].data_ptr(), prm, labels_out=label_bufs[0].data_ptr(), n=npts, on_device=True)
+        ctxs[0][0].segment(frames_dev[s % len(frames_dev)].data_ptr(), prm, labels_out=label_bufs[0][0].data_ptr(), n=npts, on_device=True)
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
-    res = ctxs[0].result
+    res = ctxs[0][0].result
 
     if rank == 0:
         value = world * args.steps * npts / elapsed / 1e6
@@ -176,13 +184,14 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t 0.2" % (args.width, args.height, npts),
-                           "frames_in_flight_per_gpu": nstreams, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
+                           "frames_in_flight_per_gpu": nstreams, "batch": nbatch, "concurrent_batches": ngroups, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
                            "label_gather": "RCCL gather to rank 0 per step" if world > 1 else "none",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
                 "single_stream_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
-    for c in ctxs:
-        c.close()
+    for grp in ctxs:
+        for c in grp:
+            c.close()
     if world > 1:
         dist.destroy_process_group()
 

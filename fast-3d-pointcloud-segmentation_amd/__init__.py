@@ -98,6 +98,9 @@ def load_library(path=None):
     lib.f3ds_set_stream.argtypes = [vp, vp]; lib.f3ds_set_stream.restype = ctypes.c_int
     lib.f3ds_segment.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.POINTER(Params), vp, ctypes.c_int, ctypes.POINTER(Result)]
     lib.f3ds_segment.restype = ctypes.c_int
+    lib.f3ds_segment_batch.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.c_int, ctypes.POINTER(Params),
+                                       ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(Result)]
+    lib.f3ds_segment_batch.restype = ctypes.c_int
     lib.f3ds_recluster.argtypes = [vp, ctypes.POINTER(Params), vp, ctypes.c_int, ctypes.POINTER(Result)]
     lib.f3ds_recluster.restype = ctypes.c_int
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
@@ -244,6 +247,33 @@ class Context:
         buf = np.zeros(nb.value, np.uint8)
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, DBG[name], buf.ctypes.data, nb.value, ctypes.byref(nb)))
         return buf.view(DBG_DTYPE[name])
+
+
+def segment_batch(ctxs, points, params, labels_out=None, n=None, on_device=False):
+    """Segment len(ctxs) independent frames at once (one context per frame, all on one GPU).
+    Host mode: points = list of (N_i,4) float32 arrays, returns a list of label arrays.
+    Device mode: points / labels_out = lists of device pointers, n = list of point counts."""
+    lib = load_library()
+    k = len(ctxs)
+    vp = ctypes.c_void_p
+    handles = (vp * k)(*[c.handle for c in ctxs])
+    results = (Result * k)()
+    if on_device:
+        pp = (vp * k)(*[vp(int(p)) for p in points]); lp = (vp * k)(*[vp(int(p)) for p in labels_out])
+        cnt = (ctypes.c_size_t * k)(*[int(x) for x in n])
+        _check(lib, lib.f3ds_segment_batch(handles, k, pp, cnt, 1, ctypes.byref(params), lp, 1, results))
+        out = None
+    else:
+        arrs = [np.ascontiguousarray(p, np.float32).reshape(-1, 4) for p in points]
+        out = [np.empty(len(a), np.uint32) for a in arrs]
+        pp = (vp * k)(*[vp(a.ctypes.data) for a in arrs]); lp = (vp * k)(*[vp(o.ctypes.data) for o in out])
+        cnt = (ctypes.c_size_t * k)(*[len(a) for a in arrs])
+        _check(lib, lib.f3ds_segment_batch(handles, k, pp, cnt, 0, ctypes.byref(params), lp, 0, results))
+        for c, a in zip(ctxs, arrs):
+            c._n = len(a)
+    for c, r in zip(ctxs, results):
+        ctypes.memmove(ctypes.byref(c.result), ctypes.byref(r), ctypes.sizeof(Result))
+    return out
 
 
 def segment(points, params=None, device=0):

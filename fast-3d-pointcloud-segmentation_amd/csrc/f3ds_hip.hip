@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/f3ds.h"
@@ -1033,7 +1034,10 @@ __device__ inline bool edge_before_k(const MergeDev& m, uint32_t e, uint32_t ke,
     EdgeHist H{m.ev_epoch, m.ev_key, m.ev_prev};
     return a_edge_before(H, e, ke, m.ehist[e], f, kf, m.ehist[f]);
 }
-__global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x) {
+__global__ __launch_bounds__(ML_THREADS) void k_merge_lds(const MergeDev* frames_m, const MergeLds* frames_x) {
+    // one workgroup per frame: a batch of frames merges concurrently inside a single dispatch
+    const MergeDev m = frames_m[blockIdx.x];
+    const MergeLds x = frames_x[blockIdx.x];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* akey = reinterpret_cast<uint32_t*>(smem);
     uint32_t* eab = akey + x.Ecap;
@@ -1059,6 +1063,12 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
     for (uint32_t g = tid; g < x.G; g += ML_THREADS) gdirty[g] = 1;
     if (tid == 0) { s_nt = 0; s_nmerges = 0; s_nevents = m.E; s_stop = 0; s_pool_end = m.S0 + 1u; }
     __syncthreads();
+#ifdef F3DS_MERGE_PROF   // per-phase shader-clock totals, printed by thread 0 (make PROF=1)
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define TPH(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tph[i] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define TPH(i) do { } while (0)
+#endif
     for (uint32_t epoch = 1;; ++epoch) {
         // ---- minima of the groups whose edges changed
         for (uint32_t g = wave; g < x.G; g += NW) {
@@ -1075,6 +1085,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
             if (lane == 0) { gkey[g] = kmin; gidx[g] = idx; gdirty[g] = 0; }
         }
         __syncthreads();
+        TPH(0);
         // ---- next = *weight_map.begin()
         if (wave == 0) {
             uint32_t kloc = KEY_DEAD;
@@ -1111,6 +1122,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
             }
         }
         __syncthreads();
+        TPH(1);
         if (s_stop) break;
         const uint32_t a = s_a, b = s_b;
         // ---- edges that touch a or b (LDS scan), leaf array of the merged region
@@ -1138,6 +1150,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
         uint32_t rows_done = 0;
         bool dedupe_done = false;
         __syncthreads();
+        TPH(2);
         const uint32_t nt = s_nt;
         // ---- voxels_new = voxels_a ++ voxels_b: gather b's rows to LDS, continue a's ordered sums
         for (uint32_t lc = 0; lc < nb; lc += ML_THREADS) {
@@ -1188,6 +1201,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
                 __syncthreads();
             }
         }
+        TPH(3);
         if (wave == 0 && lane < 9) { s_acc[lane] = acc; m.racc[(size_t)a * 12 + lane] = acc; }
         if (wave == 1 && lane < 3) { s_acc[9 + lane] = acc; m.racc[(size_t)a * 12 + 9 + lane] = acc; }
         __syncthreads();
@@ -1226,6 +1240,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
             }
         }
         __syncthreads();
+        TPH(4);
         // ---- re-weight the surviving incident edges (delta(), src/clustering.cpp:438-463)
         for (uint32_t i = tid; i < nt; i += ML_THREADS) {
             const uint32_t te = m.tl[i], e = te & 0x7fffffffu;
@@ -1256,10 +1271,17 @@ __global__ __launch_bounds__(ML_THREADS) void k_merge_lds(MergeDev m, MergeLds x
         }
         if (tid == 0) s_nt = 0;
         __syncthreads();
+        TPH(5);
         if (m.dc->error) break;
     }
     __syncthreads();
     if (tid == 0) { m.dc->n_merges = s_nmerges; m.dc->n_events = s_nevents; }
+#ifdef F3DS_MERGE_PROF
+    if (tid == 0) printf("k_merge_lds cycles/merge: groupmin %.0f argmin %.0f touched+pool %.0f gather+fold %.0f record %.0f weights %.0f (merges %u)\n",
+                         (double)tph[0] / s_nmerges, (double)tph[1] / s_nmerges, (double)tph[2] / s_nmerges, (double)tph[3] / s_nmerges, (double)tph[4] / s_nmerges,
+                         (double)tph[5] / s_nmerges, s_nmerges);
+#endif
+#undef TPH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1314,6 +1336,8 @@ struct f3ds_ctx {
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
     bool merge_in_lds = false;
+    MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
+    Buf batch_args;
 };
 
 namespace {
@@ -1397,9 +1421,10 @@ int finish_empty(f3ds_ctx* c, uint32_t* point_labels, int labels_on_device, f3ds
 }
 
 // stages 4b..6: Clustering::cluster(threshold) on the supervoxels held by the context
-int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int labels_on_device) {
+// stages 4b: everything of Clustering::cluster(threshold) up to (not including) the merge loop
+int run_cluster_front(f3ds_ctx* c, const f3ds_params* prm) {
     hipStream_t st = c->stream;
-    const uint32_t S0 = c->S0, E = c->E, n = c->n;
+    const uint32_t S0 = c->S0, E = c->E;
     // main(): set_merging / set_lambda / set_bins_num (src/supervoxel_clustering.cpp:415-423)
     float lambda = 0.5f; int bins = 500;
     if (prm->merging == F3DS_MANUAL_LAMBDA && prm->lambda != 0) { if (prm->lambda < 0 || prm->lambda > 1) return F3DS_ERR_RANGE; lambda = prm->lambda; }
@@ -1470,15 +1495,39 @@ int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int
         }
         hipLaunchKernelGGL(k_edge_weights, dim3(grid_for(E, 256)), dim3(256), 0, st, m, (const float*)deltas);
     }
-    HIPCHECK(hipEventRecord(c->ev[5], st));
-    if (use_lds) {
-        const uint32_t dyn = xl.stage_off + xl.caprows * 52u;
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(k_merge_lds, dim3(1), dim3(ML_THREADS), dyn, st, m, xl);
-    } else {
-        hipLaunchKernelGGL(k_merge, dim3(1), dim3(MG_THREADS), 0, st, m);
+    c->mdev = m; c->mlds = xl; c->merge_dyn = use_lds ? xl.stage_off + xl.caprows * 52u : 0u; c->host_lambda = lambda;
+    return F3DS_OK;
+}
+// stage 5 for a set of frames whose fronts are complete: the LDS-resident merge loops of all of them
+// run as ONE dispatch (one workgroup per frame) on `st`; frames that do not fit LDS get k_merge each.
+int merge_launch(f3ds_ctx** cs, int nctx, hipStream_t st) {
+    f3ds_ctx* c0 = cs[0];
+    std::vector<MergeDev> ms; std::vector<MergeLds> xs; uint32_t dyn = 0;
+    for (int i = 0; i < nctx; ++i) {
+        HIPCHECK(hipEventRecord(cs[i]->ev[5], st));
+        if (cs[i]->merge_in_lds) { ms.push_back(cs[i]->mdev); xs.push_back(cs[i]->mlds); if (cs[i]->merge_dyn > dyn) dyn = cs[i]->merge_dyn; }
     }
-    HIPCHECK(hipEventRecord(c->ev[6], st));
+    if (!ms.empty()) {
+        unsigned char* args;
+        const size_t bytes_m = ms.size() * sizeof(MergeDev), bytes_x = xs.size() * sizeof(MergeLds);
+        ENSURE(c0->batch_args, unsigned char, bytes_m + bytes_x, args);
+        HIPCHECK(hipMemcpyAsync(args, ms.data(), bytes_m, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(args + bytes_m, xs.data(), bytes_x, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipStreamSynchronize(st));        // the host vectors go out of scope below
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(k_merge_lds, dim3((uint32_t)ms.size()), dim3(ML_THREADS), dyn, st, (const MergeDev*)args, (const MergeLds*)(args + bytes_m));
+    }
+    for (int i = 0; i < nctx; ++i)
+        if (!cs[i]->merge_in_lds) hipLaunchKernelGGL(k_merge, dim3(1), dim3(MG_THREADS), 0, st, cs[i]->mdev);
+    for (int i = 0; i < nctx; ++i) HIPCHECK(hipEventRecord(cs[i]->ev[6], st));
+    return F3DS_OK;
+}
+// stage 6: region ids and per-point labels
+int run_cluster_tail(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int labels_on_device) {
+    hipStream_t st = c->stream;
+    const uint32_t S0 = c->S0, E = c->E, n = c->n;
+    const MergeDev& m = c->mdev;
+    const float lambda = c->host_lambda;
     uint32_t *root, *rflags, *rincl, *d_labels;
     ENSURE(c->root, uint32_t, S0 + 1, root); ENSURE(c->rflags, uint32_t, S0 + 1, rflags); ENSURE(c->rincl, uint32_t, S0 + 1, rincl);
     ENSURE(c->labels, uint32_t, n, d_labels);
@@ -1496,6 +1545,12 @@ int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int
     c->prm.color_metric = prm->color_metric; c->prm.geom_metric = prm->geom_metric; c->prm.merging = prm->merging;
     c->prm.lambda = prm->lambda; c->prm.bins = prm->bins; c->prm.threshold = prm->threshold;
     return F3DS_OK;
+}
+int run_cluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, int labels_on_device) {
+    int rc = run_cluster_front(c, prm);
+    if (rc) return rc;
+    if ((rc = merge_launch(&c, 1, c->stream))) return rc;
+    return run_cluster_tail(c, prm, point_labels, labels_on_device);
 }
 
 }  // namespace
@@ -1557,11 +1612,15 @@ int f3ds_set_stream(f3ds_ctx* c, void* hip_stream) {
     return F3DS_OK;
 }
 
-int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_device, const f3ds_params* prm, uint32_t* point_labels,
-                 int labels_on_device, f3ds_result* result) {
+}  // extern "C"
+
+namespace {
+// stages 0..4: returns 1 when the frame ended early (no voxels: labels are already written), 0 when
+// the merge stage is prepared (c->mdev / c->mlds), < 0 on error
+int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_device, const f3ds_params* prm, uint32_t* point_labels,
+                  int labels_on_device, f3ds_result* result) {
     if (!c || !prm || (!points && n_) || n_ > 0x7fffffffull) return F3DS_ERR_ARG;
     if (!(prm->voxel_res > 0) || !(prm->seed_res > 0)) return F3DS_ERR_ARG;
-    const auto t0 = std::chrono::steady_clock::now();
     HIPCHECK(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const uint32_t n = (uint32_t)n_;
@@ -1597,7 +1656,7 @@ int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_devic
     c->res.n_finite = c->h_dc->n_finite;
     if (c->h_grid->error) return c->h_grid->error;
     c->res.octree_depth = (uint32_t)c->h_grid->depth;
-    if (c->h_grid->empty || n == 0) return finish_empty(c, point_labels, labels_on_device, result);
+    if (c->h_grid->empty || n == 0) { int rc_ = finish_empty(c, point_labels, labels_on_device, result); return rc_ ? rc_ : 1; }
     const int depth = c->h_grid->depth;
     uint64_t *k0, *k1, *ks; uint32_t *v0, *v1, *vs;
     ENSURE(c->keys0, uint64_t, n, k0); ENSURE(c->keys1, uint64_t, n, k1); ENSURE(c->vals0, uint32_t, n, v0); ENSURE(c->vals1, uint32_t, n, v1);
@@ -1614,7 +1673,7 @@ int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_devic
     { int rc = sync_counters(c); if (rc) return rc; }
     const uint32_t V = c->h_dc->n_voxels;
     c->V = V; c->res.n_voxels = V;
-    if (V == 0) return finish_empty(c, point_labels, labels_on_device, result);
+    if (V == 0) { int rc_ = finish_empty(c, point_labels, labels_on_device, result); return rc_ ? rc_ : 1; }
     uint32_t *vkey, *vcount, *hvals; float* vf; int* nbr; uint64_t* hkeys;
     const uint32_t hcap = pow2_ge((size_t)V * 2 + 16);
     c->hmask = hcap - 1;
@@ -1741,11 +1800,65 @@ int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_devic
         hipLaunchKernelGGL(k_edge_init, dim3(grid_for(E, 256)), dim3(256), 0, st, (const uint64_t*)eks, E, S0, ea0, eb0);
     }
     c->have_frame = true;
-    int rc = run_cluster(c, prm, point_labels, labels_on_device);
+    int rc = run_cluster_front(c, prm);
     if (rc) { c->have_frame = false; return rc; }
-    for (int i = 0; i < 7; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) c->res.ms_stage[i] = ms; }
+    return 0;
+}
+void stage_times(f3ds_ctx* c, int first) {
+    for (int i = first; i < 7; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) c->res.ms_stage[i] = ms; }
+}
+}  // namespace
+
+extern "C" {
+
+int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_device, const f3ds_params* prm, uint32_t* point_labels,
+                 int labels_on_device, f3ds_result* result) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = segment_front(c, points, n_, points_on_device, prm, point_labels, labels_on_device, result);
+    if (rc < 0) return rc;
+    if (rc == 1) return F3DS_OK;
+    if ((rc = merge_launch(&c, 1, c->stream)) || (rc = run_cluster_tail(c, prm, point_labels, labels_on_device))) { c->have_frame = false; return rc; }
+    stage_times(c, 0);
     c->res.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (result) *result = c->res;
+    return F3DS_OK;
+}
+
+// A batch of independent frames (BASELINE.json config 5: 8 frames per GPU): the wide stages of every
+// frame run on its own context/stream from its own host thread; the merge loops -- one latency-bound
+// workgroup per frame -- are then issued as a single dispatch so that all of them overlap (separate
+// launches from more than four streams queue up behind each other on the compute pipes).
+int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, const size_t* counts, int points_on_device, const f3ds_params* prm,
+                       uint32_t* const* point_labels, int labels_on_device, f3ds_result* results) {
+    if (!ctxs || nctx <= 0 || !points || !counts || !prm) return F3DS_ERR_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> rcs((size_t)nctx, 0);
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nctx; ++i)
+            th.emplace_back([&, i]() { rcs[i] = segment_front(ctxs[i], points[i], counts[i], points_on_device, prm, point_labels ? point_labels[i] : nullptr, labels_on_device, nullptr); });
+        for (auto& t : th) t.join();
+    }
+    std::vector<f3ds_ctx*> live;
+    for (int i = 0; i < nctx; ++i) { if (rcs[i] < 0) return rcs[i]; if (rcs[i] == 0) live.push_back(ctxs[i]); }
+    if (!live.empty()) {
+        HIPCHECK(hipSetDevice(live[0]->device));
+        int rc = merge_launch(live.data(), (int)live.size(), live[0]->stream);
+        if (rc) return rc;
+        HIPCHECK(hipStreamSynchronize(live[0]->stream));
+        std::vector<std::thread> th;
+        for (int i = 0; i < nctx; ++i)
+            if (rcs[i] == 0)
+                th.emplace_back([&, i]() {
+                    (void)hipSetDevice(ctxs[i]->device);
+                    rcs[i] = run_cluster_tail(ctxs[i], prm, point_labels ? point_labels[i] : nullptr, labels_on_device);
+                    if (rcs[i]) ctxs[i]->have_frame = false; else stage_times(ctxs[i], 0);
+                });
+        for (auto& t : th) t.join();
+        for (int i = 0; i < nctx; ++i) if (rcs[i] < 0) return rcs[i];
+    }
+    const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int i = 0; i < nctx; ++i) { ctxs[i]->res.ms_total = ms; if (results) results[i] = ctxs[i]->res; }
     return F3DS_OK;
 }
 
@@ -1759,7 +1872,7 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     HIPCHECK(hipEventRecord(c->ev[4], c->stream));
     int rc = run_cluster(c, prm, point_labels, labels_on_device);
     if (rc) return rc;
-    for (int i = 4; i < 7; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) c->res.ms_stage[i] = ms; }
+    stage_times(c, 4);
     c->res.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (result) *result = c->res;
     return F3DS_OK;

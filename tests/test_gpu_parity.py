@@ -132,3 +132,18 @@ def test_cli_on_fixture(P, oracle, tmp_path):
     ox, ol, oc = oh.voxel_cloud()
     assert np.array_equal(cloud[:, :3].view(np.uint32), ox.view(np.uint32)) and np.array_equal(clab, ol)
     assert np.array_equal(cloud[:, 3].copy().view(np.uint32), oc)
+
+
+def test_batch_of_frames_matches_single_calls(P, oracle):
+    """f3ds_segment_batch: one context per frame, one merge dispatch for all of them."""
+    names = ["rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags", "rgbd_160x120"]
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.1)
+    frames = [case_points(P, n) for n in names] + [np.zeros((0, 4), np.float32)]
+    ctxs = [P.Context(0) for _ in frames]
+    got = P.segment_batch(ctxs, frames, prm)
+    for f, g, c in zip(frames, got, ctxs):
+        rc, olab, ores, _ = oracle.segment(f, prm)
+        assert rc == 0 and np.array_equal(olab, g)
+        assert c.result.n_regions == ores.n_regions and c.result.n_merges == ores.n_merges
+    for c in ctxs:
+        c.close()
