@@ -128,7 +128,7 @@ F3DS_HD float a_radius_sq(float seed_res) {
 // ---------------------------------------------------------------------------------------------
 struct SweepView {
     int V;
-    const int* nbr;           // V x 27, -1 = none
+    const int* nbrT;          // 27 x V (slot-major: lanes of consecutive voxels read consecutive words), -1 = none
     const float* vf;          // V x 12 voxel features: xyz rgb normal pad
     const uint32_t* owner;    // V, sweep-start owner label (0 = none)
     const float* dist;        // V, sweep-start VoxelData::distance_
@@ -137,27 +137,35 @@ struct SweepView {
     // overwrites owner_; when two seeds resolve to the same voxel the earlier helper keeps a leaf
     // it does not own.  Such a leaf still expands and still counts in updateCentroid until the
     // helper steals it for real.  ghost_head[v] = first helper (label) with an active ghost on v,
-    // ghost_next[label] chains further ones (0 ends the chain).
+    // ghost_next[label] chains further ones (0 ends the chain); *n_ghosts = active ghosts (the
+    // chains are not even looked at once it is zero, which is the normal state after sweep 1).
     const uint32_t* ghost_head;   // V
     const uint32_t* ghost_next;   // S0+1
+    const uint32_t* n_ghosts;
     float seed_res, w_normal, w_color, w_spatial;
 };
+F3DS_HD int a_nbr(const SweepView& s, int v, int k) { return s.nbrT[(size_t)k * (size_t)s.V + (size_t)v]; }
 F3DS_HD float a_helper_dist(const SweepView& s, uint32_t g, int v) {
     return n_voxel_distance(s.hc + (size_t)g * 12, s.vf + (size_t)v * 12, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
 }
 #define F3DS_R_STACK 24
-#define F3DS_R_UNKNOWN 0
 #define F3DS_R_TRUE 1
 #define F3DS_R_FALSE 2
-// R(w) for an owned voxel w, memoised in `memo` (one byte per voxel, F3DS_R_UNKNOWN before the
-// sweep).  Concurrent callers may race on memo entries: every writer stores the same value, and a
-// stale "unknown" only costs a recomputation.  *overflow is set when the dependency chain is
-// deeper than the explicit stack.
-F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, int* overflow) {
+#define F3DS_OWNR_RTRUE 0x80000000u
+// memo byte = (tag << 2) | value; tag = (sweep % 63) + 1 so that entries written in an earlier sweep
+// read as "unknown" without clearing the array (it is zeroed before sweep 0, 63, 126, ...)
+F3DS_HD unsigned char a_sweep_tag(unsigned sweep) { return (unsigned char)((sweep % 63u) + 1u); }
+F3DS_HD bool a_sweep_needs_clear(unsigned sweep) { return sweep % 63u == 0u; }
+// R(w) for an owned voxel w, memoised in `memo` (one byte per voxel).  Concurrent callers may race
+// on memo entries: every writer stores the same value, and a stale "unknown" only costs a
+// recomputation.  *overflow is set when the dependency chain is deeper than the explicit stack.
+F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, unsigned char tag, int* overflow) {
+    const unsigned char T = (unsigned char)(tag << 2);
     {
         const unsigned char m0 = memo[w0];
-        if (m0 != F3DS_R_UNKNOWN) return m0 == F3DS_R_TRUE;
+        if ((m0 & 0xFC) == T) return (m0 & 3) == F3DS_R_TRUE;
     }
+    const bool ghosts = *s.n_ghosts != 0u;
     int node[F3DS_R_STACK];
     int slot[F3DS_R_STACK];
     int sp = 0;
@@ -169,20 +177,22 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, int* over
         bool pushed = false, stolen = false;
         uint32_t g_cached = 0; bool cached_less = false;
         for (int k = slot[sp]; k < 27; ++k) {
-            int u = s.nbr[(size_t)w * 27 + k];
+            int u = a_nbr(s, w, k);
             if (u < 0) continue;
             // a lower helper with a ghost leaf on u always reaches w at its turn
-            for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
-                if (gg < h && a_helper_dist(s, gg, w) < dw) { stolen = true; break; }
-            if (stolen) break;
+            if (ghosts) {
+                for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
+                    if (gg < h && a_helper_dist(s, gg, w) < dw) { stolen = true; break; }
+                if (stolen) break;
+            }
             uint32_t g = s.owner[u];
             if (g == 0u || g >= h) continue;
             if (g != g_cached) { g_cached = g; cached_less = a_helper_dist(s, g, w) < dw; }
             if (!cached_less) continue;
             // helper g steals w through u provided u is still g's at g's turn, i.e. R(u)
             const unsigned char mu = memo[u];
-            if (mu == F3DS_R_TRUE) { stolen = true; break; }
-            if (mu == F3DS_R_FALSE) continue;
+            if (mu == (T | F3DS_R_TRUE)) { stolen = true; break; }
+            if (mu == (T | F3DS_R_FALSE)) continue;
             slot[sp] = k + 1;
             if (sp + 1 >= F3DS_R_STACK) { *overflow = 1; return true; }
             ++sp; node[sp] = u; slot[sp] = 0;
@@ -192,7 +202,7 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, int* over
         if (pushed) continue;
         bool r = !stolen;              // true: nobody steals node[sp] before its owner's turn
         for (;;) {
-            memo[node[sp]] = r ? F3DS_R_TRUE : F3DS_R_FALSE;
+            memo[node[sp]] = (unsigned char)(T | (r ? F3DS_R_TRUE : F3DS_R_FALSE));
             if (sp == 0) return r;
             --sp;
             if (r) { r = false; continue; }   // child still owned -> parent stolen -> R(parent) = false
@@ -200,31 +210,42 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, int* over
         }
     }
 }
-// state of voxel v after the sweep; ghost_done[g] is set when helper g turns its ghost leaf on v
-// into a real one (only the thread of v writes entries of helpers ghosting v)
-F3DS_HD void a_claim(const SweepView& s, const unsigned char* R, int v, uint32_t* owner_out, float* dist_out,
-                     unsigned char* ghost_done) {
+// state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
+// (written by the R pass for every voxel), so a neighbour costs one gather.  ghost_done[g] is set
+// when helper g turns its ghost leaf on v into a real one (only the thread of v writes it).
+F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* owner_out, float* dist_out, unsigned char* ghost_done) {
+    const bool ghosts = *s.n_ghosts != 0u;
     uint32_t o = s.owner[v];
     float d = s.dist[v];
+    uint32_t cand[27];
+    for (int k = 0; k < 27; ++k) {
+        const int u = a_nbr(s, v, k);
+        const uint32_t x = u >= 0 ? ownR[u] : 0u;
+        cand[k] = (x & F3DS_OWNR_RTRUE) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
+    }
     uint32_t last = 0;
     for (;;) {
         uint32_t g = 0xFFFFFFFFu;     // smallest candidate label above `last`
         for (int k = 0; k < 27; ++k) {
-            int u = s.nbr[(size_t)v * 27 + k];
-            if (u < 0) continue;
-            uint32_t gu = s.owner[u];
-            if (gu > last && gu < g && R[u] == F3DS_R_TRUE) g = gu;
-            for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
-                if (gg > last && gg < g) g = gg;
+            const uint32_t gu = cand[k];
+            if (gu > last && gu < g) g = gu;
         }
+        if (ghosts)
+            for (int k = 0; k < 27; ++k) {
+                const int u = a_nbr(s, v, k);
+                if (u < 0) continue;
+                for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
+                    if (gg > last && gg < g) g = gg;
+            }
         if (g == 0xFFFFFFFFu) break;
         last = g;
         if (g == o) continue;          // neighbor_voxel.owner_ == this
         float dg = a_helper_dist(s, g, v);
         if (dg < d) {
             d = dg; o = g;
-            for (uint32_t gg = s.ghost_head[v]; gg != 0u; gg = s.ghost_next[gg])
-                if (gg == g) ghost_done[g] = 1;
+            if (ghosts)
+                for (uint32_t gg = s.ghost_head[v]; gg != 0u; gg = s.ghost_next[gg])
+                    if (gg == g) ghost_done[g] = 1;
         }
     }
     *owner_out = o; *dist_out = d;

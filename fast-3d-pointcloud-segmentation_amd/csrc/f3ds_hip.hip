@@ -68,7 +68,8 @@ struct DevCounters {
     int r_overflow;
     float lambda;
     uint32_t seg_count;      // scratch for generic segmenting
-    uint32_t pad[3];
+    uint32_t n_ghosts;       // helpers that still hold a ghost leaf (sweeps)
+    uint32_t pad[2];
 };
 
 constexpr uint64_t HASH_EMPTY = 0xFFFFFFFFFFFFFFFFull;
@@ -383,8 +384,9 @@ __device__ inline int hash_find(const uint64_t* hkeys, const uint32_t* hvals, ui
 // stage 1: neighbour table and voxel normals
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_neighbors(const uint32_t* vkey, const DevCounters* dc, const GridInfo* gp, const uint64_t* hkeys,
-                                                  const uint32_t* hvals, uint32_t hmask, int* nbr) {
-    const uint32_t total = dc->n_voxels * 27u;
+                                                  const uint32_t* hvals, uint32_t hmask, int* nbr, int* nbrT) {
+    const uint32_t V = dc->n_voxels;
+    const uint32_t total = V * 27u;
     const unsigned max_key = gp->max_key;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const uint32_t v = t / 27u, s = t - v * 27u;
@@ -395,7 +397,9 @@ __global__ __launch_bounds__(256) void k_neighbors(const uint32_t* vkey, const D
             if (q < 0 || q > (long long)max_key) ok = false;
             k[a] = (unsigned)q;
         }
-        nbr[t] = ok ? hash_find(hkeys, hvals, hmask, n_pack_key(k[0], k[1], k[2])) : -1;
+        const int u = ok ? hash_find(hkeys, hvals, hmask, n_pack_key(k[0], k[1], k[2])) : -1;
+        nbr[t] = u;                              // row-major: a voxel's 27 slots together (normals, adjacency)
+        nbrT[(size_t)s * V + v] = u;             // slot-major: coalesced across consecutive voxels (sweeps)
     }
 }
 __device__ inline void cov_add(float acc[9], const float4 q) {
@@ -600,41 +604,62 @@ __global__ __launch_bounds__(256) void k_helper_init(const int* seed_kept, uint3
         hlo[i] = (uint32_t)v; hhi[i] = (uint32_t)v; hcount[i] = 1;
     }
 }
-__global__ __launch_bounds__(256) void k_ghost_relink(uint32_t S0, const int* ghost_vox, const unsigned char* ghost_active, uint32_t* ghost_head,
-                                                     uint32_t* ghost_next) {
-    for (uint32_t h = 1 + threadIdx.x; h <= S0; h += blockDim.x) if (ghost_vox[h] >= 0) ghost_head[ghost_vox[h]] = 0u;
+// The sweep kernels are batched: blockIdx.y selects the frame, so the sweeps of a whole batch of
+// frames are four dispatches per sweep instead of four per frame and sweep.
+struct SweepFrame {
+    SweepView sv;                   // sv.owner / sv.dist: the sweep-start state
+    unsigned char* R; uint32_t* ownR;
+    uint32_t* owner_out; float* dist_out;
+    unsigned char *ghost_done, *ghost_active; int* ghost_vox; uint32_t *ghost_head, *ghost_next;
+    uint32_t *hlo, *hhi, *hcount; float* hc; DevCounters* dc; uint32_t S0;
+};
+__global__ __launch_bounds__(256) void k_ghost_relink(const SweepFrame* F) {
+    const SweepFrame& f = F[blockIdx.y];
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    for (uint32_t h = 1 + threadIdx.x; h <= f.S0; h += blockDim.x) if (f.ghost_vox[h] >= 0) f.ghost_head[f.ghost_vox[h]] = 0u;
     __syncthreads();
-    for (uint32_t h = 1 + threadIdx.x; h <= S0; h += blockDim.x)
-        if (ghost_active[h]) ghost_next[h] = atomicExch(&ghost_head[ghost_vox[h]], h);
+    uint32_t mine = 0;
+    for (uint32_t h = 1 + threadIdx.x; h <= f.S0; h += blockDim.x)
+        if (f.ghost_active[h]) { f.ghost_next[h] = atomicExch(&f.ghost_head[f.ghost_vox[h]], h); mine++; }
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) f.dc->n_ghosts = s_n;
 }
-__global__ __launch_bounds__(256) void k_sweep_R(SweepView s, unsigned char* R, DevCounters* dc) {
+__global__ __launch_bounds__(256) void k_sweep_R(const SweepFrame* F, unsigned char tag) {
+    const SweepFrame& f = F[blockIdx.y];
+    const SweepView s = f.sv;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < s.V; v += gridDim.x * blockDim.x) {
         int overflow = 0;
-        if (s.owner[v]) a_eval_R(s, v, R, &overflow);
-        if (overflow) dc->r_overflow = 1;
+        const uint32_t o = s.owner[v];
+        const bool r = o ? a_eval_R(s, v, f.R, tag, &overflow) : false;
+        f.ownR[v] = o | (r ? F3DS_OWNR_RTRUE : 0u);
+        if (overflow) f.dc->r_overflow = 1;
     }
 }
-__global__ __launch_bounds__(256) void k_sweep_claim(SweepView s, const unsigned char* R, uint32_t* owner_out, float* dist_out, unsigned char* ghost_done,
-                                                    uint32_t* hlo, uint32_t* hhi) {
+__global__ __launch_bounds__(256) void k_sweep_claim(const SweepFrame* F) {
+    const SweepFrame& f = F[blockIdx.y];
+    const SweepView s = f.sv;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < s.V; v += gridDim.x * blockDim.x) {
         uint32_t o; float d;
-        a_claim(s, R, v, &o, &d, ghost_done);
-        owner_out[v] = o; dist_out[v] = d;
-        if (o != s.owner[v] && o != 0u) { atomicMin(&hlo[o], (uint32_t)v); atomicMax(&hhi[o], (uint32_t)v); }
+        a_claim(s, f.ownR, v, &o, &d, f.ghost_done);
+        f.owner_out[v] = o; f.dist_out[v] = d;
+        if (o != s.owner[v] && o != 0u) { atomicMin(&f.hlo[o], (uint32_t)v); atomicMax(&f.hhi[o], (uint32_t)v); }
     }
 }
 // one wave per helper: SupervoxelHelper::updateCentroid.  The helper's leaves are the voxels it
 // owns inside its ordinal window [lo,hi] (plus its ghost leaf); they are visited in ascending
 // ordinal, i.e. std::set<leaf, compareLeaves> order, 64 candidates at a time.
-__global__ __launch_bounds__(64) void k_centroid(const float* vf, const uint32_t* owner, uint32_t S0, const uint32_t* hlo, const uint32_t* hhi,
-                                                const int* ghost_vox, unsigned char* ghost_active, unsigned char* ghost_done, uint32_t* hcount, float* hc) {
+__global__ __launch_bounds__(64) void k_centroid(const SweepFrame* F) {
     __shared__ __attribute__((aligned(16))) float tile[64][12];
+    const SweepFrame& f = F[blockIdx.y];
     const uint32_t h = blockIdx.x + 1u;
-    if (h > S0) return;
+    if (h > f.S0) return;
+    const float* vf = f.sv.vf; const uint32_t* owner = f.owner_out;
     const int lane = lane_id();
-    bool gact = ghost_active[h] && !ghost_done[h];
-    const int gv = gact ? ghost_vox[h] : -1;
-    const uint32_t lo = hlo[h], hi = hhi[h];
+    bool gact = f.ghost_active[h] && !f.ghost_done[h];
+    const int gv = gact ? f.ghost_vox[h] : -1;
+    const uint32_t lo = f.hlo[h], hi = f.hhi[h];
     float acc = 0.0f;
     uint32_t count = 0;
     for (uint32_t base = lo & ~63u; base <= hi; base += 64u) {
@@ -654,7 +679,7 @@ __global__ __launch_bounds__(64) void k_centroid(const float* vf, const uint32_t
         count += (uint32_t)cnt;
         __syncthreads();
     }
-    if (lane == 0) { ghost_active[h] = gact ? 1 : 0; ghost_done[h] = 0; hcount[h] = count; }
+    if (lane == 0) { f.ghost_active[h] = gact ? 1 : 0; f.ghost_done[h] = 0; f.hcount[h] = count; }
     if (count == 0) return;
     float sum[9];
 #pragma unroll
@@ -662,10 +687,9 @@ __global__ __launch_bounds__(64) void k_centroid(const float* vf, const uint32_t
     if (lane == 0) {
         float row[12];
         a_centroid_finish(sum, count, row);
-        for (int k = 0; k < 12; ++k) hc[(size_t)h * 12 + k] = row[k];
+        for (int k = 0; k < 12; ++k) f.hc[(size_t)h * 12 + k] = row[k];
     }
 }
-
 // ------------------------------------------------------------------------------------------------
 // stage 4: supervoxel payload, adjacency, initial weights
 // ------------------------------------------------------------------------------------------------
@@ -809,11 +833,15 @@ __global__ __launch_bounds__(64) void k_lambda(uint32_t E, const float* deltas, 
         const float vc = i < E ? deltas[svals[i]] : 0.0f;
         const float vg = i < E ? deltas[svals[(size_t)E + i]] : 0.0f;
         const int nb = E - base < 64u ? (int)(E - base) : 64;
-        for (int j = 0; j < nb; ++j) {
-            const float dcj = __shfl(vc, j, 64), dgj = __shfl(vg, j, 64);
-            const float d = lane == 0 ? dcj : dgj;
-            count++;
-            mean_d = mean_d + (1 / count) * (d - mean_d);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            if (j < nb) {
+                const float dcj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vc), j));
+                const float dgj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vg), j));
+                const float d = lane == 0 ? dcj : dgj;
+                count++;
+                mean_d = mean_d + (1 / count) * (d - mean_d);
+            }
         }
     }
     const float mean_c = __shfl(mean_d, 0, 64), mean_g = __shfl(mean_d, 1, 64);
@@ -1337,7 +1365,7 @@ struct f3ds_ctx {
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
     bool merge_in_lds = false;
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
-    Buf batch_args;
+    Buf batch_args, sweep_args, nbrT, ownR;
 };
 
 namespace {
@@ -1617,8 +1645,8 @@ int f3ds_set_stream(f3ds_ctx* c, void* hip_stream) {
 namespace {
 // stages 0..4: returns 1 when the frame ended early (no voxels: labels are already written), 0 when
 // the merge stage is prepared (c->mdev / c->mlds), < 0 on error
-int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_device, const f3ds_params* prm, uint32_t* point_labels,
-                  int labels_on_device, f3ds_result* result) {
+int segment_front_a(f3ds_ctx* c, const void* points, size_t n_, int points_on_device, const f3ds_params* prm, uint32_t* point_labels,
+                    int labels_on_device, f3ds_result* result) {
     if (!c || !prm || (!points && n_) || n_ > 0x7fffffffull) return F3DS_ERR_ARG;
     if (!(prm->voxel_res > 0) || !(prm->seed_res > 0)) return F3DS_ERR_ARG;
     HIPCHECK(hipSetDevice(c->device));
@@ -1679,6 +1707,7 @@ int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_devi
     c->hmask = hcap - 1;
     ENSURE(c->vkey, uint32_t, (size_t)V * 3, vkey); ENSURE(c->vcount, uint32_t, V, vcount); ENSURE(c->vf, float, (size_t)V * 12, vf);
     ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->hkeys, uint64_t, hcap, hkeys); ENSURE(c->hvals, uint32_t, hcap, hvals);
+    int* nbrT; ENSURE(c->nbrT, int, (size_t)V * 27, nbrT);
     HIPCHECK(hipMemsetAsync(pt_voxel, 0xFF, (size_t)n * 4, st));
     HIPCHECK(hipMemsetAsync(hkeys, 0xFF, (size_t)hcap * 8, st));
     hipLaunchKernelGGL(k_voxel_accum, dim3(grid_for(V, 256)), dim3(256), 0, st, d_pts, (const uint64_t*)ks, (const uint32_t*)vs, (const uint32_t*)seg_start,
@@ -1686,7 +1715,7 @@ int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_devi
     HIPCHECK(hipEventRecord(c->ev[1], st));
     // ---- stage 1: neighbours + normals
     hipLaunchKernelGGL(k_neighbors, dim3(grid_for((size_t)V * 27, 256)), dim3(256), 0, st, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid,
-                       (const uint64_t*)hkeys, (const uint32_t*)hvals, c->hmask, nbr);
+                       (const uint64_t*)hkeys, (const uint32_t*)hvals, c->hmask, nbr, nbrT);
     hipLaunchKernelGGL(k_normals, dim3(grid_for(V, 256)), dim3(256), 0, st, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
     HIPCHECK(hipEventRecord(c->ev[2], st));
     // ---- stage 2: seeds
@@ -1737,6 +1766,7 @@ int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_devi
     // ---- stage 3: helpers + sweeps
     uint32_t *owner0, *owner1, *hcount, *hlo, *hhi, *ghost_head, *ghost_next; float *dist0, *dist1, *hc; unsigned char *R, *ghost_active, *ghost_done; int* ghost_vox;
     ENSURE(c->owner0, uint32_t, V, owner0); ENSURE(c->owner1, uint32_t, V, owner1); ENSURE(c->dist0, float, V, dist0); ENSURE(c->dist1, float, V, dist1);
+    uint32_t* ownR_; ENSURE(c->ownR, uint32_t, V, ownR_);
     ENSURE(c->R, unsigned char, V, R); ENSURE(c->hc, float, (size_t)(S0 + 1) * 12, hc); ENSURE(c->hcount, uint32_t, S0 + 1, hcount);
     ENSURE(c->hlo, uint32_t, S0 + 1, hlo); ENSURE(c->hhi, uint32_t, S0 + 1, hhi); ENSURE(c->ghost_vox, int, S0 + 1, ghost_vox);
     ENSURE(c->ghost_active, unsigned char, S0 + 1, ghost_active); ENSURE(c->ghost_done, unsigned char, S0 + 1, ghost_done);
@@ -1748,20 +1778,58 @@ int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_devi
     if (S0) hipLaunchKernelGGL(k_helper_own, dim3(grid_for(S0, 256)), dim3(256), 0, st, (const int*)seed_kept, S0, owner0);
     hipLaunchKernelGGL(k_helper_init, dim3(grid_for(S0 + 1, 256)), dim3(256), 0, st, (const int*)seed_kept, S0, (const uint32_t*)owner0, ghost_vox, ghost_active, ghost_done,
                        hlo, hhi, hcount, hc);
-    if (S0) {
-        for (uint32_t t = 0; t < sweeps; ++t) {
-            hipLaunchKernelGGL(k_ghost_relink, dim3(1), dim3(256), 0, st, S0, (const int*)ghost_vox, (const unsigned char*)ghost_active, ghost_head, ghost_next);
-            SweepView sv{(int)V, nbr, vf, owner0, dist0, hc, ghost_head, ghost_next, prm->seed_res, prm->w_normal, prm->w_color, prm->w_spatial};
-            HIPCHECK(hipMemsetAsync(R, 0, V, st));
-            hipLaunchKernelGGL(k_sweep_R, dim3(grid_for(V, 256)), dim3(256), 0, st, sv, R, c->d_dc);
-            hipLaunchKernelGGL(k_sweep_claim, dim3(grid_for(V, 256)), dim3(256), 0, st, sv, (const unsigned char*)R, owner1, dist1, ghost_done, hlo, hhi);
-            std::swap(owner0, owner1); std::swap(dist0, dist1);
-            std::swap(c->owner0, c->owner1); std::swap(c->dist0, c->dist1);
-            hipLaunchKernelGGL(k_centroid, dim3(S0), dim3(64), 0, st, (const float*)vf, (const uint32_t*)owner0, S0, (const uint32_t*)hlo, (const uint32_t*)hhi,
-                               (const int*)ghost_vox, ghost_active, ghost_done, hcount, hc);
+    HIPCHECK(hipMemsetAsync(R, 0, V, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// stage 3b: the label-propagation sweeps of every frame in `fr`, in lockstep, on one stream
+int run_sweeps(std::vector<f3ds_ctx*>& fr, hipStream_t st) {
+    if (fr.empty()) return F3DS_OK;
+    f3ds_ctx* c0 = fr[0];
+    const uint32_t sweeps = c0->res.sweeps;
+    uint32_t maxV = 0, maxS = 0;
+    for (f3ds_ctx* c : fr) { if (c->V > maxV) maxV = c->V; if (c->S0 > maxS) maxS = c->S0; }
+    const uint32_t nf = (uint32_t)fr.size();
+    SweepFrame* dargs;
+    ENSURE(c0->sweep_args, SweepFrame, nf, dargs);
+    std::vector<SweepFrame> args(nf);
+    for (uint32_t t = 0; t < sweeps && maxS; ++t) {
+        for (uint32_t i = 0; i < nf; ++i) {
+            f3ds_ctx* c = fr[i];
+            const f3ds_params& prm = c->prm;
+            SweepFrame& a = args[i];
+            a.sv = SweepView{(int)c->V, (const int*)c->nbrT.p, (const float*)c->vf.p, (const uint32_t*)c->owner0.p, (const float*)c->dist0.p, (const float*)c->hc.p,
+                             (const uint32_t*)c->ghost_head.p, (const uint32_t*)c->ghost_next.p, (const uint32_t*)&c->d_dc->n_ghosts, prm.seed_res, prm.w_normal,
+                             prm.w_color, prm.w_spatial};
+            a.R = (unsigned char*)c->R.p; a.ownR = (uint32_t*)c->ownR.p; a.owner_out = (uint32_t*)c->owner1.p; a.dist_out = (float*)c->dist1.p;
+            a.ghost_done = (unsigned char*)c->ghost_done.p; a.ghost_active = (unsigned char*)c->ghost_active.p; a.ghost_vox = (int*)c->ghost_vox.p;
+            a.ghost_head = (uint32_t*)c->ghost_head.p; a.ghost_next = (uint32_t*)c->ghost_next.p;
+            a.hlo = (uint32_t*)c->hlo.p; a.hhi = (uint32_t*)c->hhi.p; a.hcount = (uint32_t*)c->hcount.p; a.hc = (float*)c->hc.p; a.dc = c->d_dc; a.S0 = c->S0;
+            if (t > 0 && a_sweep_needs_clear(t)) HIPCHECK(hipMemsetAsync(a.R, 0, c->V, st));
         }
+        HIPCHECK(hipMemcpyAsync(dargs, args.data(), nf * sizeof(SweepFrame), hipMemcpyHostToDevice, st));
+        const unsigned char tag = a_sweep_tag(t);
+        hipLaunchKernelGGL(k_ghost_relink, dim3(1, nf), dim3(256), 0, st, (const SweepFrame*)dargs);
+        hipLaunchKernelGGL(k_sweep_R, dim3(grid_for(maxV, 256), nf), dim3(256), 0, st, (const SweepFrame*)dargs, tag);
+        hipLaunchKernelGGL(k_sweep_claim, dim3(grid_for(maxV, 256), nf), dim3(256), 0, st, (const SweepFrame*)dargs);
+        hipLaunchKernelGGL(k_centroid, dim3(maxS, nf), dim3(64), 0, st, (const SweepFrame*)dargs);
+        for (f3ds_ctx* c : fr) { std::swap(c->owner0, c->owner1); std::swap(c->dist0, c->dist1); }
     }
-    HIPCHECK(hipEventRecord(c->ev[4], st));
+    for (f3ds_ctx* c : fr) HIPCHECK(hipEventRecord(c->ev[4], st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return F3DS_OK;
+}
+
+// stage 4: supervoxel payload, adjacency, merge set-up (after the sweeps)
+int segment_front_b(f3ds_ctx* c, const f3ds_params* prm) {
+    HIPCHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const uint32_t V = c->V, S0 = c->S0;
+    const uint32_t hcap = c->hmask + 1u;
+    uint32_t *owner0 = (uint32_t*)c->owner0.p, *hcount = (uint32_t*)c->hcount.p, *hlo = (uint32_t*)c->hlo.p, *hhi = (uint32_t*)c->hhi.p;
+    float *hc = (float*)c->hc.p, *vf = (float*)c->vf.p; int *ghost_vox = (int*)c->ghost_vox.p, *nbr = (int*)c->nbr.p;
+    unsigned char* ghost_active = (unsigned char*)c->ghost_active.p;
     // ---- stage 4: supervoxel payload, adjacency
     uint32_t* loff; ENSURE(c->loff, uint32_t, S0 + 2, loff);
     { int rc = scan_u32(c, hcount, loff + 1, S0 + 1); if (rc) return rc; }     // loff[h+1] = inclusive => loff[h] = exclusive
@@ -1802,6 +1870,7 @@ int segment_front(f3ds_ctx* c, const void* points, size_t n_, int points_on_devi
     c->have_frame = true;
     int rc = run_cluster_front(c, prm);
     if (rc) { c->have_frame = false; return rc; }
+    HIPCHECK(hipStreamSynchronize(st));      // the merge dispatch may run on another context's stream
     return 0;
 }
 void stage_times(f3ds_ctx* c, int first) {
@@ -1813,48 +1882,47 @@ extern "C" {
 
 int f3ds_segment(f3ds_ctx* c, const void* points, size_t n_, int points_on_device, const f3ds_params* prm, uint32_t* point_labels,
                  int labels_on_device, f3ds_result* result) {
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = segment_front(c, points, n_, points_on_device, prm, point_labels, labels_on_device, result);
-    if (rc < 0) return rc;
-    if (rc == 1) return F3DS_OK;
-    if ((rc = merge_launch(&c, 1, c->stream)) || (rc = run_cluster_tail(c, prm, point_labels, labels_on_device))) { c->have_frame = false; return rc; }
-    stage_times(c, 0);
-    c->res.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (result) *result = c->res;
-    return F3DS_OK;
+    const void* pp[1] = {points}; const size_t cnt[1] = {n_}; uint32_t* lp[1] = {point_labels};
+    return f3ds_segment_batch(&c, 1, pp, cnt, points_on_device, prm, lp, labels_on_device, result);
 }
 
-// A batch of independent frames (BASELINE.json config 5: 8 frames per GPU): the wide stages of every
-// frame run on its own context/stream from its own host thread; the merge loops -- one latency-bound
-// workgroup per frame -- are then issued as a single dispatch so that all of them overlap (separate
-// launches from more than four streams queue up behind each other on the compute pipes).
+// A batch of independent frames (BASELINE.json config 5: 8 frames per GPU).  Phases:
+//   A1 per frame, own stream + host thread: voxelise, normals, seeds, helpers
+//   A2 all frames in lockstep: the label-propagation sweeps as batched dispatches (grid.y = frame)
+//   A3 per frame: supervoxel payload, adjacency, initial weights
+//   B  all frames: the merge loops as ONE dispatch, one workgroup per frame (separate launches from
+//      more than a handful of streams queue up behind each other on the compute pipes)
+//   C  per frame: region ids, per-point labels, copy-out
 int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, const size_t* counts, int points_on_device, const f3ds_params* prm,
                        uint32_t* const* point_labels, int labels_on_device, f3ds_result* results) {
     if (!ctxs || nctx <= 0 || !points || !counts || !prm) return F3DS_ERR_ARG;
+    for (int i = 0; i < nctx; ++i) if (!ctxs[i]) return F3DS_ERR_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int> rcs((size_t)nctx, 0);
-    {
+    auto parallel = [&](auto&& fn) {
+        if (nctx == 1) { fn(0); return; }
         std::vector<std::thread> th;
-        for (int i = 0; i < nctx; ++i)
-            th.emplace_back([&, i]() { rcs[i] = segment_front(ctxs[i], points[i], counts[i], points_on_device, prm, point_labels ? point_labels[i] : nullptr, labels_on_device, nullptr); });
+        for (int i = 0; i < nctx; ++i) th.emplace_back([&, i]() { fn(i); });
         for (auto& t : th) t.join();
-    }
+    };
+    parallel([&](int i) { rcs[i] = segment_front_a(ctxs[i], points[i], counts[i], points_on_device, prm, point_labels ? point_labels[i] : nullptr, labels_on_device, nullptr); });
     std::vector<f3ds_ctx*> live;
     for (int i = 0; i < nctx; ++i) { if (rcs[i] < 0) return rcs[i]; if (rcs[i] == 0) live.push_back(ctxs[i]); }
     if (!live.empty()) {
         HIPCHECK(hipSetDevice(live[0]->device));
-        int rc = merge_launch(live.data(), (int)live.size(), live[0]->stream);
+        int rc = run_sweeps(live, live[0]->stream);
         if (rc) return rc;
+        parallel([&](int i) { if (rcs[i] == 0) rcs[i] = segment_front_b(ctxs[i], prm); });
+        for (int i = 0; i < nctx; ++i) if (rcs[i] < 0) return rcs[i];
+        HIPCHECK(hipSetDevice(live[0]->device));
+        if ((rc = merge_launch(live.data(), (int)live.size(), live[0]->stream))) return rc;
         HIPCHECK(hipStreamSynchronize(live[0]->stream));
-        std::vector<std::thread> th;
-        for (int i = 0; i < nctx; ++i)
-            if (rcs[i] == 0)
-                th.emplace_back([&, i]() {
-                    (void)hipSetDevice(ctxs[i]->device);
-                    rcs[i] = run_cluster_tail(ctxs[i], prm, point_labels ? point_labels[i] : nullptr, labels_on_device);
-                    if (rcs[i]) ctxs[i]->have_frame = false; else stage_times(ctxs[i], 0);
-                });
-        for (auto& t : th) t.join();
+        parallel([&](int i) {
+            if (rcs[i] != 0) return;
+            (void)hipSetDevice(ctxs[i]->device);
+            rcs[i] = run_cluster_tail(ctxs[i], prm, point_labels ? point_labels[i] : nullptr, labels_on_device);
+            if (rcs[i]) ctxs[i]->have_frame = false; else stage_times(ctxs[i], 0);
+        });
         for (int i = 0; i < nctx; ++i) if (rcs[i] < 0) return rcs[i];
     }
     const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

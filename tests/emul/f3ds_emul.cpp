@@ -234,19 +234,24 @@ int stage_sweeps(f3ds_emul& E) {
     int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
     E.res.sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0u;
     std::vector<unsigned char> R(V), done(S0 + 1);
-    std::vector<uint32_t> owner2(V), ghost_head(V, 0u), ghost_next(S0 + 1, 0u);
+    std::vector<uint32_t> owner2(V), ghost_head(V, 0u), ghost_next(S0 + 1, 0u), ownR(V);
+    std::vector<int> nbrT((size_t)V * 27);
+    for (int v = 0; v < V; ++v) for (int k = 0; k < 27; ++k) nbrT[(size_t)k * V + v] = E.nbr[(size_t)v * 27 + k];
     std::vector<float> dist2(V);
     for (uint32_t t = 0; t < E.res.sweeps; ++t) {
         for (int h = 1; h <= S0; ++h) if (E.ghost_vox[h] >= 0) ghost_head[E.ghost_vox[h]] = 0u;
         for (int h = 1; h <= S0; ++h) if (E.ghost_active[h]) { ghost_next[h] = ghost_head[E.ghost_vox[h]]; ghost_head[E.ghost_vox[h]] = (uint32_t)h; }
-        SweepView s{V, E.nbr.data(), E.vf.data(), E.owner.data(), E.dist.data(), E.hc.data(), ghost_head.data(), ghost_next.data(),
+        uint32_t n_ghosts = 0;
+        for (int h = 1; h <= S0; ++h) n_ghosts += E.ghost_active[h];
+        SweepView s{V, nbrT.data(), E.vf.data(), E.owner.data(), E.dist.data(), E.hc.data(), ghost_head.data(), ghost_next.data(), &n_ghosts,
                     prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
         int overflow = 0;
-        std::fill(R.begin(), R.end(), (unsigned char)F3DS_R_UNKNOWN);
-        for (int v = 0; v < V; ++v) if (E.owner[v]) a_eval_R(s, v, R.data(), &overflow);
+        const unsigned char tag = a_sweep_tag(t);
+        if (a_sweep_needs_clear(t)) std::fill(R.begin(), R.end(), (unsigned char)0);
+        for (int v = 0; v < V; ++v) { bool r = E.owner[v] ? a_eval_R(s, v, R.data(), tag, &overflow) : false; ownR[v] = E.owner[v] | (r ? F3DS_OWNR_RTRUE : 0u); }
         if (overflow) return F3DS_ERR_UNSUPPORTED;
         std::fill(done.begin(), done.end(), 0);
-        for (int v = 0; v < V; ++v) a_claim(s, R.data(), v, &owner2[v], &dist2[v], done.data());
+        for (int v = 0; v < V; ++v) a_claim(s, ownR.data(), v, &owner2[v], &dist2[v], done.data());
         E.owner.swap(owner2); E.dist.swap(dist2);
         for (int h = 1; h <= S0; ++h) if (done[h]) E.ghost_active[h] = 0;
         std::vector<float> sum((size_t)(S0 + 1) * 9, 0.0f);
