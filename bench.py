@@ -4,19 +4,22 @@
 A *step* is one pass of the whole hot path (voxelise -> normals -> seeds -> sweeps -> adjacency ->
 merge -> per-point labels) over one 1,000,000-point XYZRGBA frame that is already resident in
 HBM when the timed region starts (config 2 of BASELINE.md: 1000x1000 pinhole frame, 3 % NaN,
-flags ``-v 0.008 -s 0.08 --AL --CVX -t 0.2``).  Steps run through ``--streams`` independent
-f3ds contexts (one HIP stream + one host thread each) because a frame contains two latency-bound
-single-workgroup stages (label-propagation sweeps, merge loop) that only fill the chip when
-several frames are in flight; every step still runs the full path on its own frame.
+flags ``-v 0.008 -s 0.08 --AL --CVX -t 0.2``).  Frames are independent, and a single frame holds
+two inherently sequential pieces (16 Gauss-Seidel sweeps, ~2800 dependent merges), so the steps
+are issued ``--batch`` frames at a time through ``f3ds_segment_batch`` -- every kernel of the path
+is then ONE dispatch for the whole batch (grid.y = frame; the merge loops run one workgroup per
+frame) -- and ``--groups`` such calls are in flight from host threads so that one batch's wide
+kernels overlap another batch's merge dispatch.  Every step still runs the complete path on its
+own frame; the JSON also reports the latency of a single frame with nothing else in flight.
 
-N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU, frames are
-independent so each rank segments its own frames (weak scaling, no data-path collective except
-the label output: one RCCL gather of the uint32 label buffers to rank 0 per step).
+N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU, each rank segments
+its own frames (weak scaling, no data-path collective); the label output is one RCCL gather of
+the uint32 label buffers to rank 0 per frame.
 
 The JSON line also carries
-  roofline     -- dominant kernel (by device time, HIP events on the kernel's own stream inside
-                  libf3ds): achieved = 20 B/point x points per launch / mean launch duration,
-                  against the 8 TB/s HBM3E peak;
+  roofline     -- dominant kernel by device time (HIP events recorded on the batch's stream inside
+                  libf3ds around each stage): achieved = 20 B/point x points per launch / mean launch
+                  duration, against the 8 TB/s HBM3E peak;
   cpu_baseline -- the CPU oracle (single thread, kind "port": the reference needs PCL/OpenCV and
                   cannot be built here) on one frame of the same workload, rank 0 at N=1 only.
 """
@@ -50,9 +53,9 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--batch", type=int, default=16, help="frames per f3ds_segment_batch call")
+    ap.add_argument("--steps", type=int, default=1152)
+    ap.add_argument("--warmup", type=int, default=288)
+    ap.add_argument("--batch", type=int, default=96, help="frames per f3ds_segment_batch call")
     ap.add_argument("--groups", type=int, default=3, help="batch calls in flight per GPU")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames to cycle through")
     ap.add_argument("--width", type=int, default=1000)

@@ -55,7 +55,7 @@ __device__ __forceinline__ void unpack_call(const ArgPack<T, Ts...>& p, Done... 
 
 template <class K, class Pack>
 __global__ __launch_bounds__(K::BLOCK) void k_batched(const Pack* frames) {
-    const Pack p = frames[blockIdx.y];
+    const Pack p = frames[f3ds_frame()];      // XCD-aware (frame, block) mapping: f3ds_kernels.inc
     unpack_call<K>(p);
 }
 
