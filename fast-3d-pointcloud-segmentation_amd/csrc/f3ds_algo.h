@@ -159,12 +159,16 @@ F3DS_HD bool a_sweep_needs_clear(unsigned sweep) { return sweep % 63u == 0u; }
 // R(w) for an owned voxel w, memoised in `memo` (one byte per voxel).  Concurrent callers may race
 // on memo entries: every writer stores the same value, and a stale "unknown" only costs a
 // recomputation.  *overflow is set when the dependency chain is deeper than the explicit stack.
-F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, unsigned char tag, int* overflow) {
+// a_eval_R_chain is the general form (explicit DFS stack); a_eval_R first scans w's neighbourhood
+// with scalars only and falls into the chain walker just when some R(u) is really unknown, which
+// keeps the stack arrays (scratch memory on the GPU) off the common path.
+#if defined(__HIPCC__)
+#define F3DS_NOINLINE __attribute__((noinline))
+#else
+#define F3DS_NOINLINE
+#endif
+F3DS_HD F3DS_NOINLINE bool a_eval_R_chain(const SweepView& s, int w0, unsigned char* memo, unsigned char tag, int* overflow) {
     const unsigned char T = (unsigned char)(tag << 2);
-    {
-        const unsigned char m0 = memo[w0];
-        if ((m0 & 0xFC) == T) return (m0 & 3) == F3DS_R_TRUE;
-    }
     const bool ghosts = *s.n_ghosts != 0u;
     int node[F3DS_R_STACK];
     int slot[F3DS_R_STACK];
@@ -209,6 +213,44 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w0, unsigned char* memo, unsigned 
             break;                     // child was stolen first -> parent keeps scanning
         }
     }
+}
+F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned char tag, int* overflow) {
+    const unsigned char T = (unsigned char)(tag << 2);
+    {
+        const unsigned char m0 = memo[w];
+        if ((m0 & 0xFC) == T) return (m0 & 3) == F3DS_R_TRUE;
+    }
+    if (*s.n_ghosts != 0u) return a_eval_R_chain(s, w, memo, tag, overflow);     // ghost leaves: general walker
+    const uint32_t h = s.owner[w];
+    const float dw = s.dist[w];
+    // neighbours owned by a lower label (the only possible thieves before h's turn); every lane of a
+    // wave first collects them, then the expensive distance is evaluated once per distinct owner
+    int nu[27]; uint32_t og[27];
+    for (int k = 0; k < 27; ++k) {
+        const int u = a_nbr(s, w, k);
+        const uint32_t g = u >= 0 ? s.owner[u] : 0u;
+        nu[k] = u; og[k] = (g != 0u && g < h) ? g : 0u;
+    }
+    bool stolen = false, unknown = false;
+    uint32_t last = 0;
+    for (;;) {
+        uint32_t g = 0xFFFFFFFFu;
+        for (int k = 0; k < 27; ++k) if (og[k] > last && og[k] < g) g = og[k];
+        if (g == 0xFFFFFFFFu) break;
+        last = g;
+        if (!(a_helper_dist(s, g, w) < dw)) continue;
+        // g steals w through a leaf u of g that is still g's at g's turn, i.e. R(u)
+        for (int k = 0; k < 27; ++k)
+            if (og[k] == g) {
+                const unsigned char mu = memo[nu[k]];
+                if (mu == (T | F3DS_R_TRUE)) stolen = true;
+                else if (mu != (T | F3DS_R_FALSE)) unknown = true;
+            }
+        if (stolen) break;
+    }
+    if (!stolen && unknown) return a_eval_R_chain(s, w, memo, tag, overflow);     // some R(u) still has to be derived
+    memo[w] = (unsigned char)(T | (stolen ? F3DS_R_FALSE : F3DS_R_TRUE));
+    return !stolen;
 }
 // state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
 // (written by the R pass for every voxel), so a neighbour costs one gather.  ghost_done[g] is set
