@@ -410,8 +410,8 @@ bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl) {
     xl->G = xl->Ecap / 64u;
     const uint32_t lds_fixed = xl->Ecap * 8u + xl->G * 8u + (2u * ML_THREADS + 1u) * 4u + ((xl->G + 15u) & ~15u);
     xl->stage_off = (lds_fixed + 15u) & ~15u;
-    const uint32_t lds_budget = 160u * 1024u - 4096u;
-    const bool ok = S0 <= 65535u && xl->stage_off + 128u * 52u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
+    const uint32_t lds_budget = 160u * 1024u - 8192u;     // static LDS of the kernel (scan scratch, dirty list, scalars)
+    const bool ok = S0 <= 65534u && xl->stage_off + 128u * 52u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
     xl->caprows = ok ? (lds_budget - xl->stage_off) / 52u : 128u;
     if (xl->caprows > 2048u) xl->caprows = 2048u;
     return ok;
