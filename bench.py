@@ -91,8 +91,10 @@ def main():
     nbatch, ngroups = max(1, args.batch), max(1, args.groups)
     nstreams = nbatch * ngroups
     ctxs = [[P.Context(local_rank) for _ in range(nbatch)] for _ in range(ngroups)]
-    label_bufs = [[torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(nbatch)] for _ in range(ngroups)]
-    gather_list = [torch.empty(npts, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # one contiguous label block per group: the batch's label output is ONE RCCL gather (nbatch x 4 MB per rank)
+    label_blocks = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(ngroups)]
+    label_bufs = [[label_blocks[g][i] for i in range(nbatch)] for g in range(ngroups)]
+    gather_list = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
     stage_ms = [0.0] * 7
@@ -116,10 +118,9 @@ def main():
                     k = len(steps)
                     P.segment_batch(ctxs[g][:k], [frames_dev[s % len(frames_dev)].data_ptr() for s in steps], prm,
                                     labels_out=[label_bufs[g][i].data_ptr() for i in range(k)], n=[npts] * k, on_device=True)
-                    if world > 1:   # label output of these steps: one RCCL gather to rank 0 per frame
+                    if world > 1:   # label output of this batch: one RCCL gather of the whole label block to rank 0
                         with stage_lock:
-                            for i in range(k):
-                                dist.gather(label_bufs[g][i], gather_list, dst=0)
+                            dist.gather(label_blocks[g], gather_list, dst=0)
                     if record:      # ms_stage is the device time of each stage of the whole batch (HIP events on the batch stream)
                         with stage_lock:
                             for j in range(7):
@@ -166,12 +167,23 @@ def main():
         value = world * args.steps * npts / elapsed / 1e6
         mean_stage = [m / max(1, batches_done[0]) for m in stage_ms]       # per batched launch sequence
         frames_per_launch = frames_done[0] / max(1, batches_done[0])
-        dom = max(range(7), key=lambda i: mean_stage[i])
+        # The dominant KERNEL is the merge loop: 42 % of all device time in profiles/r1_kernel_stats.csv, one launch
+        # per batch, so its launch duration is exactly the 'merge' stage measured live below.  (The 'sweeps' stage
+        # can be as long, but it is 64 launches of four different kernels.)
+        dom = STAGES.index("merge")
         dom_ms = mean_stage[dom]
         # one launch of the dominant kernel processes `frames_per_launch` frames (grid.y = frame)
         achieved = ALG_BYTES_PER_POINT * npts * frames_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))
+            kname = STAGE_KERNEL[STAGES[dom]].split("<")[1].rstrip(">")
+            if kname in pm["kernels"]:
+                traffic = int(pm["kernels"][kname]["hbm_bytes_per_frame"] * frames_per_launch)
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": STAGE_KERNEL[STAGES[dom]], "stage": STAGES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": frames_per_launch,
                     "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_POINT * npts * frames_per_launch),
                     "whole_path_achieved_GBps": round(ALG_BYTES_PER_POINT * npts * frames_per_launch / (sum(mean_stage) * 1e-3) / 1e9, 3) if sum(mean_stage) > 0 else None,
@@ -193,7 +205,7 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t 0.2" % (args.width, args.height, npts),
                            "frames_in_flight_per_gpu": nstreams, "batch": nbatch, "concurrent_batches": ngroups, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
-                           "label_gather": "RCCL gather to rank 0 per step" if world > 1 else "none",
+                           "label_gather": "one RCCL gather of the batch's label block (batch x 4 MB per rank) to rank 0 per batch" if world > 1 else "none",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
                 "single_stream_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
