@@ -77,6 +77,14 @@ class Result(ctypes.Structure):
 _lib = None
 
 
+class Performance(ctypes.Structure):
+    """performanceSet (include/supervoxel_clustering/testing.h:40-48)."""
+    _fields_ = [(k, ctypes.c_float) for k in ("voi", "precision", "recall", "fscore", "wov", "fpr", "fnr")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 def load_library(path=None):
     """Load libf3ds.so (built by ``__graft_entry__.build()`` / ``make -C csrc``).  Raises if missing."""
     global _lib
@@ -103,6 +111,10 @@ def load_library(path=None):
     lib.f3ds_segment_batch.restype = ctypes.c_int
     lib.f3ds_recluster.argtypes = [vp, ctypes.POINTER(Params), vp, ctypes.c_int, ctypes.POINTER(Result)]
     lib.f3ds_recluster.restype = ctypes.c_int
+    lib.f3ds_evaluate.argtypes = [vp, vp, ctypes.POINTER(Performance)]; lib.f3ds_evaluate.restype = ctypes.c_int
+    lib.f3ds_auto_threshold.argtypes = [vp, ctypes.POINTER(Params), vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, sz, ctypes.POINTER(sz),
+                                        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(Performance), vp, ctypes.c_int, ctypes.POINTER(Result)]
+    lib.f3ds_auto_threshold.restype = ctypes.c_int
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
     lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
     lib.f3ds_pcd_read.argtypes = [ctypes.c_char_p, vp, vp, sz, ctypes.POINTER(sz), u32p, u32p]; lib.f3ds_pcd_read.restype = ctypes.c_int
@@ -113,6 +125,10 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+(OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_DEPTH, ERR_LOGIC, ERR_RANGE, ERR_UNSUPPORTED, ERR_IO, ERR_EQ_BIN,
+ ERR_CAPACITY) = (0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)       # include/f3ds.h:37-50
 
 
 def _check(lib, rc):
@@ -198,6 +214,7 @@ class Context:
         self.handle = h
         self.device = device
         self.result = Result()
+        self._n = 0
 
     def close(self):
         if getattr(self, "handle", None):
@@ -233,6 +250,29 @@ class Context:
         labels = np.empty(self._n, np.uint32)
         _check(self.lib, self.lib.f3ds_recluster(self.handle, ctypes.byref(params), labels.ctypes.data, 0, ctypes.byref(self.result)))
         return labels
+
+    def evaluate(self, truth_point_labels):
+        """Scores of the current segmentation against per-point ground-truth labels (Testing::eval_performance)."""
+        t = np.ascontiguousarray(truth_point_labels, np.uint32)
+        if len(t) != self._n:
+            raise ValueError("one ground-truth label per input point is required")
+        out = Performance()
+        _check(self.lib, self.lib.f3ds_evaluate(self.handle, t.ctypes.data, ctypes.byref(out)))
+        return out
+
+    def auto_threshold(self, params, truth_point_labels, start=0.8, end=1.0, step=0.005):
+        """all_thresh + best_thresh; returns (best threshold, best scores, {threshold: scores}, point labels)."""
+        t = np.ascontiguousarray(truth_point_labels, np.uint32)
+        if len(t) != self._n:
+            raise ValueError("one ground-truth label per input point is required")
+        cap = 4096
+        ts = np.zeros(cap, np.float32); ps = (Performance * cap)()
+        n = ctypes.c_size_t(); bt = ctypes.c_float(); bp = Performance()
+        labels = np.empty(self._n, np.uint32)
+        _check(self.lib, self.lib.f3ds_auto_threshold(self.handle, ctypes.byref(params), t.ctypes.data, start, end, step, ts.ctypes.data, ps, cap,
+                                                      ctypes.byref(n), ctypes.byref(bt), ctypes.byref(bp), labels.ctypes.data, 0, ctypes.byref(self.result)))
+        m = min(n.value, cap)
+        return bt.value, bp, {float(ts[i]): ps[i].as_dict() for i in range(m)}, labels
 
     def voxel_cloud(self):
         n = ctypes.c_size_t()
@@ -384,6 +424,31 @@ class Clustering:
             self._labels = ctx.recluster(self._params(threshold))
         if self.merging_type == ADAPTIVE_LAMBDA:
             self.lambda_ = ctx.result.lambda_
+
+    def all_thresh(self, truth_point_labels, start_thresh, end_thresh, step_thresh):      # clustering.cpp:691-741
+        """{threshold: performanceSet dict} over the sweep; the state is left clustered at best_thresh of it."""
+        if self._super is None:
+            raise LogicError(-5, "Cannot call 'all_thresh' before setting an initial state with 'set_initialstate'")
+        ctx = self._super.ctx
+        if not self._segmented:
+            ctx.segment(self._super.cloud, self._params(start_thresh if 0 <= start_thresh <= 1 else 0.0))
+            self._segmented = True
+        bt, bp, table, self._labels = ctx.auto_threshold(self._params(0.0), truth_point_labels, start_thresh, end_thresh, step_thresh)
+        if self.merging_type == ADAPTIVE_LAMBDA:
+            self.lambda_ = ctx.result.lambda_
+        return table
+
+    @staticmethod
+    def best_thresh(all_performances):             # clustering.cpp:748-774: first strictly greater F-score, (0, zeros) if none
+        best_t, best_p = 0.0, {k: 0.0 for k in ("voi", "precision", "recall", "fscore", "wov", "fpr", "fnr")}
+        for t in sorted(all_performances):
+            if all_performances[t]["fscore"] > best_p["fscore"]:
+                best_t, best_p = t, all_performances[t]
+        return best_t, best_p
+
+    def eval_performance(self, truth_point_labels):
+        """Testing(get_labeled_cloud(), truth_cloud).eval_performance() (src/supervoxel_clustering.cpp:462-463)."""
+        return self._super.ctx.evaluate(truth_point_labels).as_dict()
 
     def get_labeled_cloud(self):                   # clustering.cpp:640-663 -> (xyz, label)
         xyz, lab, _ = self._super.ctx.voxel_cloud()

@@ -4,8 +4,9 @@
 //
 // Kept from the reference: -d/-p, -v -s -c -z -n, -t, --RGB --CVX --ML --AL --EQ, -r, -f, --NT, --V.
 // Added (additive): -o <pcd> coloured voxel cloud (Clustering::get_colored_cloud), --labels <file>
-// per-point uint32 region ids, --gpu <id>.  Not built yet: the automatic threshold sweep that runs
-// when -t is omitted (needs the Testing evaluator) -- the tool says so and exits 1.
+// per-point uint32 region ids, --gpu <id>.  Without -t the threshold is chosen by the ground-truth sweep
+// (all_thresh 0.8..1 step 0.005 + best_thresh, :428-437) and the <-f name>_*.csv score files are written
+// (:471, manageAllPerformances); every file is scored against its `label` field (:462-463).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -116,10 +117,6 @@ int main(int argc, char** argv) {
     if (find_switch(argc, argv, "-o")) parse(argc, argv, "-o", out_pcd);
     if (find_switch(argc, argv, "--labels")) parse(argc, argv, "--labels", out_labels);
     if (find_switch(argc, argv, "--gpu")) parse(argc, argv, "--gpu", gpu);
-    if (!thresh_specified) {
-        fprintf(stderr, "automatic threshold selection needs the evaluation sweep, which this build does not include yet; pass -t <threshold>\n");
-        return 1;
-    }
     prm.use_transform = !disable_transform;
     prm.color_metric = rgb ? F3DS_RGB_EUCL : F3DS_LAB_CIEDE00;
     prm.geom_metric = cvx ? F3DS_CONVEX_NORMALS_DIFF : F3DS_NORMALS_DIFF;
@@ -128,6 +125,8 @@ int main(int argc, char** argv) {
     f3ds_ctx* ctx = nullptr;
     int rc = f3ds_create(gpu, &ctx);
     if (rc) { fprintf(stderr, "f3ds_create: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); return 1; }
+    std::vector<std::vector<f3ds_performance>> all_performances;
+    std::vector<f3ds_performance> best_performances;
     for (const std::string& file : file_list) {
         printf("Loading pointcloud from PCD file '%s'...\n", file.c_str());
         size_t n = 0;
@@ -141,9 +140,9 @@ int main(int argc, char** argv) {
             size_t k = 0;
             for (size_t i = 0; i < n; ++i) {
                 float z = pts[i].z < 0 ? std::fabs(pts[i].z) : pts[i].z;
-                if (gt[i] != (uint32_t)label_to_be_removed && !(z != z)) { pts[k] = pts[i]; ++k; }
+                if (gt[i] != (uint32_t)label_to_be_removed && !(z != z)) { pts[k] = pts[i]; gt[k] = gt[i]; ++k; }
             }
-            pts.resize(k); n = k;
+            pts.resize(k); gt.resize(k); n = k;
         }
         printf("Pointcloud loaded\nExtracting supervoxels...\n");
         std::vector<uint32_t> labels(n);
@@ -152,7 +151,22 @@ int main(int argc, char** argv) {
         if (rc) { fprintf(stderr, "f3ds_segment: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
         printf("Found %u supervoxels\nGetting supervoxel adjacency...\nSegmentation initialization...\n", res.n_supervoxels);
         if (ml || al) DEBUG("Lambda: %f\n", res.lambda);
+        if (!thresh_specified) {                                // all_thresh + best_thresh (:428-437)
+            std::vector<float> ts(4096); std::vector<f3ds_performance> ps(4096);
+            size_t nt = 0; float best_t = 0; f3ds_performance best_p;
+            rc = f3ds_auto_threshold(ctx, &prm, gt.data(), 0.8f, 1.0f, 0.005f, ts.data(), ps.data(), ts.size(), &nt, &best_t, &best_p, labels.data(), 0, &res);
+            if (rc) { fprintf(stderr, "f3ds_auto_threshold: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
+            ps.resize(nt < ps.size() ? nt : ps.size());
+            all_performances.push_back(ps);
+            printf("Using best threshold: %f (F-score %f, voi %f)\n", best_t, best_p.fscore, best_p.voi);
+            prm.threshold = best_t;
+        }
         printf("Initialization complete\nStarting clustering...\nClustering complete\n");
+        printf("Initializing testing suite...\n");
+        f3ds_performance score;
+        rc = f3ds_evaluate(ctx, gt.data(), &score);             // Testing(get_labeled_cloud(), truth).eval_performance() (:462-463)
+        if (rc) { fprintf(stderr, "f3ds_evaluate: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
+        best_performances.push_back(score);
         printf("%llu points, %u voxels, %u supervoxels, %u adjacencies, %u merges -> %u regions (%.3f ms on GPU %d)\n",
                (unsigned long long)res.n_points, res.n_voxels, res.n_supervoxels, res.n_edges, res.n_merges, res.n_regions, res.ms_total, gpu);
         if (!out_pcd.empty() || !out_labels.empty()) {
@@ -173,5 +187,25 @@ int main(int argc, char** argv) {
         }
     }
     f3ds_destroy(ctx);
+    // manageAllPerformances (:475-518): one line per file, one "value;" per threshold
+    {
+        const char* names[7] = {"voi", "precision", "recall", "fscore", "wov", "fpr", "fnr"};
+        for (int k = 0; k < 7; ++k) {
+            FILE* f = fopen((test_filename + "_" + names[k] + ".csv").c_str(), "w");
+            if (!f) continue;
+            for (const auto& row : all_performances) {
+                for (const f3ds_performance& p : row) fprintf(f, "%g;", (&p.voi)[k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
+    // printBestPerformances (:520-557); its running mean uses the integer 1/count, so with several files
+    // the "average" it prints is the first file's scores -- kept as is
+    if (!best_performances.empty()) {
+        const f3ds_performance& p = best_performances.size() == 1 ? best_performances.back() : best_performances.front();
+        printf("%s:\nVOI\t%f\nPrec.\t%f\nRecall\t%f\nF-score\t%f\nWOv\t%f\nFPR\t%f\nFNR\t%f\n",
+               best_performances.size() == 1 ? "Scores" : "Average scores", p.voi, p.precision, p.recall, p.fscore, p.wov, p.fpr, p.fnr);
+    }
     return 0;
 }

@@ -28,6 +28,7 @@
 #include "../../include/f3ds.h"
 #include "f3ds_algo.h"
 #include "f3ds_glasbey.h"
+#include "f3ds_eval.h"
 
 using namespace f3ds;
 
@@ -117,7 +118,9 @@ struct f3ds_ctx {
     Buf owner0, owner1, ownR, dist0, dist1, R, hc, hcount, hlo, hhi, ghost_vox, ghost_active, ghost_done, ghost_head, ghost_next;
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
+    Buf glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
+    std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
 
 namespace {
@@ -848,4 +851,128 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
         if (!buf.empty()) memcpy(dst, buf.data(), buf.size());
     }
     return F3DS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ground-truth evaluation and the automatic threshold (reference main():387-447, Clustering::all_thresh
+// / best_thresh clustering.cpp:691-774, Testing src/testing.cpp).  Not on the per-frame hot path.
+// ------------------------------------------------------------------------------------------------
+namespace {
+// truth label of every voxel: label colours averaged per voxel on the GPU, distinct colours numbered
+// in first-appearance (leaf) order on the host (color2label, clustering.cpp:823-846)
+int eval_truth(f3ds_ctx* c, const uint32_t* truth_point_labels) {
+    const uint32_t n = c->n, V = c->V;
+    uint32_t *lut, *tp, *tsum, *tcol, *tlab;
+    ENSURE(c->glut, uint32_t, 256, lut); ENSURE(c->truth_pts, uint32_t, n, tp); ENSURE(c->tsum, uint32_t, (size_t)V * 3, tsum);
+    ENSURE(c->tcol, uint32_t, V, tcol); ENSURE(c->tlab, uint32_t, V, tlab);
+    HIPCHECK(hipMemcpyAsync(lut, f3ds_glasbey_256, 1024, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemcpyAsync(tp, truth_point_labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(hipMemsetAsync(tsum, 0, (size_t)V * 12, c->stream));
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    c->cmds.clear(); c->blob.clear();
+    rec<d_truth_accum>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)tp, (const uint32_t*)lut, tsum);
+    rec<d_truth_color>(c, grid_for(V, 256), 0u, V, (const uint32_t*)tsum, (const uint32_t*)c->vcount.p, tcol);
+    int rc = flush_sync(b);
+    if (rc) return rc;
+    std::vector<uint32_t> col;
+    if ((rc = fetch(c, c->tcol, V, col))) return rc;
+    std::map<uint32_t, uint32_t> ids;
+    c->tsize.clear();
+    for (uint32_t v = 0; v < V; ++v) {
+        auto it = ids.find(col[v]);
+        uint32_t l;
+        if (it == ids.end()) { l = (uint32_t)c->tsize.size(); ids.insert({col[v], l}); c->tsize.push_back(0); } else l = it->second;
+        col[v] = l; c->tsize[l]++;
+    }
+    HIPCHECK(hipMemcpy(tlab, col.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+    return F3DS_OK;
+}
+// scores of the segmentation described by (root, incl): incl[root[h]]-1 is the segment of supervoxel h
+int eval_scores(f3ds_ctx* c, const uint32_t* d_root, const uint32_t* d_incl, uint32_t K, f3ds_performance* out) {
+    const uint32_t V = c->V, M = (uint32_t)c->tsize.size();
+    if (K == 0 || M == 0) return F3DS_ERR_ARG;                         // std::invalid_argument, testing.cpp:414,431
+    if ((uint64_t)K * M > (1ull << 26)) return F3DS_ERR_UNSUPPORTED;
+    uint32_t *tab, *ssz;
+    ENSURE(c->ctab, uint32_t, (size_t)K * M, tab); ENSURE(c->csize, uint32_t, K, ssz);
+    HIPCHECK(hipMemsetAsync(tab, 0, (size_t)K * M * 4, c->stream));
+    HIPCHECK(hipMemsetAsync(ssz, 0, (size_t)K * 4, c->stream));
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    c->cmds.clear(); c->blob.clear();
+    rec<d_contingency>(c, grid_for(V, 256), 0u, V, M, (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
+    rec<d_contingency_ghost>(c, grid_for(c->S0, 256), 0u, c->S0, M, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p,
+                             (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
+    int rc = flush_sync(b);
+    if (rc) return rc;
+    std::vector<uint32_t> table, ssize;
+    if ((rc = fetch(c, c->ctab, (size_t)K * M, table)) || (rc = fetch(c, c->csize, K, ssize))) return rc;
+    *out = f3ds_scores_from_table(table, ssize, c->tsize, V);
+    return F3DS_OK;
+}
+}  // namespace
+
+extern "C" int f3ds_evaluate(f3ds_ctx* c, const uint32_t* truth_point_labels, f3ds_performance* out) {
+    if (!c || !truth_point_labels || !out) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    int rc = eval_truth(c, truth_point_labels);
+    if (rc) return rc;
+    return eval_scores(c, (const uint32_t*)c->root.p, (const uint32_t*)c->rincl.p, c->res.n_regions, out);
+}
+
+extern "C" int f3ds_auto_threshold(f3ds_ctx* c, const f3ds_params* prm, const uint32_t* truth_point_labels, float start, float end, float step,
+                                   float* thresholds, f3ds_performance* scores, size_t cap, size_t* n_out, float* best_threshold,
+                                   f3ds_performance* best_score, uint32_t* point_labels, int labels_on_device, f3ds_result* result) {
+    if (!c || !prm || !truth_point_labels) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    if (start < 0 || start > 1 || end < 0 || end > 1 || !(step > 0) || step > 1) return F3DS_ERR_RANGE;   // clustering.cpp:693-700 (step 0 never ends there)
+    if (start > end) { float t = start; start = end; end = t; }
+    std::vector<float> ts{start};
+    for (float t = start + step; t <= end; t += step) ts.push_back(t);
+    // Clustering::cluster(state, t) continues one merge sequence, so every threshold's segmentation is a
+    // prefix of the merges done at the largest one: merge once, then replay the log on the host
+    f3ds_params p = *prm;
+    p.threshold = ts.back();
+    int rc = f3ds_recluster(c, &p, nullptr, 0, nullptr);
+    if (rc) return rc;
+    const uint32_t S0 = c->S0, nm = c->res.n_merges;
+    std::vector<uint32_t> log, hcount;
+    if ((rc = fetch(c, c->merges, (size_t)nm * 3, log)) || (rc = fetch(c, c->hcount, S0 + 1, hcount))) return rc;
+    if ((rc = eval_truth(c, truth_point_labels))) return rc;
+    uint32_t *d_root, *d_incl;
+    ENSURE(c->eroot, uint32_t, S0 + 1, d_root); ENSURE(c->eincl, uint32_t, S0 + 1, d_incl);
+    std::vector<uint32_t> parent(S0 + 1), root(S0 + 1), incl(S0 + 1);
+    for (uint32_t h = 0; h <= S0; ++h) parent[h] = h;
+    std::map<float, f3ds_performance> all;
+    uint32_t done = 0;
+    for (float t : ts) {
+        while (done < nm) {
+            float w; memcpy(&w, &log[(size_t)done * 3 + 2], 4);
+            if (!(w < t)) break;
+            parent[log[(size_t)done * 3 + 1]] = log[(size_t)done * 3];
+            done++;
+        }
+        uint32_t K = 0;
+        for (uint32_t h = 0; h <= S0; ++h) {
+            uint32_t r = h;
+            while (parent[r] != r) r = parent[r];
+            root[h] = r;
+            if (h > 0 && hcount[h] && r == h) K++;
+            incl[h] = K;
+        }
+        HIPCHECK(hipMemcpy(d_root, root.data(), (size_t)(S0 + 1) * 4, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(d_incl, incl.data(), (size_t)(S0 + 1) * 4, hipMemcpyHostToDevice));
+        f3ds_performance pf;
+        if ((rc = eval_scores(c, d_root, d_incl, K, &pf))) return rc;
+        all.insert({t, pf});
+    }
+    float bt = 0; f3ds_performance bp; memset(&bp, 0, sizeof bp);
+    for (auto& kv : all) if (kv.second.fscore > bp.fscore) { bp = kv.second; bt = kv.first; }     // best_thresh, :748-774
+    size_t k = 0;
+    for (auto& kv : all) { if (k < cap) { if (thresholds) thresholds[k] = kv.first; if (scores) scores[k] = kv.second; } k++; }
+    if (n_out) *n_out = k;
+    if (best_threshold) *best_threshold = bt;
+    if (best_score) *best_score = bp;
+    p.threshold = bt;
+    return f3ds_recluster(c, &p, point_labels, labels_on_device, result);
 }

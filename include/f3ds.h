@@ -164,6 +164,26 @@ enum {
 };
 int f3ds_get_debug(f3ds_ctx* ctx, int what, void* dst, size_t cap_bytes, size_t* bytes_out);
 
+/* ---- evaluation against ground truth and automatic threshold (the path run when -t is omitted) ----
+ * Mirrors Testing::eval_performance (src/testing.cpp:239-406) and Clustering::all_thresh / best_thresh
+ * (src/clustering.cpp:691-774) on the frame of the last f3ds_segment call.  truth_point_labels holds
+ * one ground-truth label per input point (the PCD `label` field).  The truth cloud is built like
+ * main() does (src/supervoxel_clustering.cpp:387-400): points coloured by label -> voxel mean colour ->
+ * one truth label per distinct voxel colour, in first-appearance order. */
+typedef struct f3ds_performance { float voi, precision, recall, fscore, wov, fpr, fnr; } f3ds_performance;
+
+/* scores of the current segmentation (Testing(get_labeled_cloud(), truth).eval_performance()) */
+int f3ds_evaluate(f3ds_ctx* ctx, const uint32_t* truth_point_labels, f3ds_performance* out);
+
+/* all_thresh(start, end, step) + best_thresh: clusters at every threshold start, start+step, ... <= end
+ * (float accumulation as in the reference), scores each, returns the best by F-score and leaves the
+ * context clustered at that threshold (point_labels receives its labels; may be NULL).
+ * thresholds / scores (capacity cap) receive the sweep; n_out its length. */
+int f3ds_auto_threshold(f3ds_ctx* ctx, const f3ds_params* params, const uint32_t* truth_point_labels,
+                        float start, float end, float step, float* thresholds, f3ds_performance* scores,
+                        size_t cap, size_t* n_out, float* best_threshold, f3ds_performance* best_score,
+                        uint32_t* point_labels, int labels_on_device, f3ds_result* result);
+
 /* ---- host-side helpers either side of the path (no GPU needed) -------------------------- */
 
 /* PCD v0.7 reader (ascii / binary / binary_compressed), replaces pcl::io::loadPCDFile at

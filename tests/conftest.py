@@ -72,6 +72,26 @@ class Handle:
         rc = self.chk.fn("cluster")(self.h, ctypes.byref(params), ctypes.c_void_p(labels.ctypes.data), ctypes.byref(res))
         return rc, labels, res
 
+    def evaluate(self, truth):
+        P = self.chk.P
+        t = np.ascontiguousarray(truth, np.uint32)
+        out = P.Performance()
+        rc = self.chk.fn("evaluate")(self.h, ctypes.c_void_p(t.ctypes.data), ctypes.byref(out))
+        return rc, out
+
+    def auto_threshold(self, params, truth, n, start=0.8, end=1.0, step=0.005):
+        P = self.chk.P
+        t = np.ascontiguousarray(truth, np.uint32)
+        cap = 4096
+        ts = np.zeros(cap, np.float32); ps = (P.Performance * cap)()
+        cnt = ctypes.c_size_t(); bt = ctypes.c_float(); bp = P.Performance()
+        labels = np.empty(n, np.uint32)
+        rc = self.chk.fn("auto_threshold")(self.h, ctypes.byref(params), ctypes.c_void_p(t.ctypes.data), ctypes.c_float(start), ctypes.c_float(end),
+                                           ctypes.c_float(step), ctypes.c_void_p(ts.ctypes.data), ps, ctypes.c_size_t(cap), ctypes.byref(cnt),
+                                           ctypes.byref(bt), ctypes.byref(bp), ctypes.c_void_p(labels.ctypes.data))
+        table = {float(ts[i]): ps[i].as_dict() for i in range(min(cnt.value, cap))}
+        return rc, bt.value, bp, table, labels
+
     def voxel_cloud(self):
         n = ctypes.c_size_t()
         self.chk.fn("voxel_cloud")(self.h, None, None, None, ctypes.c_size_t(0), ctypes.byref(n))
