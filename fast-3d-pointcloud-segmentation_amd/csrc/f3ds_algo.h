@@ -252,6 +252,30 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
     memo[w] = (unsigned char)(T | (stolen ? F3DS_R_FALSE : F3DS_R_TRUE));
     return !stolen;
 }
+// One application of the defining equation of R to voxel w, reading the neighbours' R from bit 31 of
+// ownR instead of deriving it: the incremental sweeps (f3ds_kernels.inc, "dirty tiles") iterate this
+// to the fixed point, which is unique because R(w) only depends on R of voxels with a lower owner.
+// Not usable while ghost leaves are active (those sweeps run the chain walker).
+F3DS_HD bool a_eval_R_step(const SweepView& s, const uint32_t* ownR, int w) {
+    const uint32_t h = s.owner[w];
+    if (h == 0u) return false;
+    const float dw = s.dist[w];
+    uint32_t og[27];
+    for (int k = 0; k < 27; ++k) {
+        const int u = a_nbr(s, w, k);
+        uint32_t g = 0u;
+        if (u >= 0) { g = s.owner[u]; if (!(g != 0u && g < h && (ownR[u] & F3DS_OWNR_RTRUE))) g = 0u; }
+        og[k] = g;       // lower helper that still holds u at its turn (as far as ownR knows)
+    }
+    uint32_t last = 0;
+    for (;;) {
+        uint32_t g = 0xFFFFFFFFu;
+        for (int k = 0; k < 27; ++k) if (og[k] > last && og[k] < g) g = og[k];
+        if (g == 0xFFFFFFFFu) return true;
+        last = g;
+        if (a_helper_dist(s, g, w) < dw) return false;
+    }
+}
 // state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
 // (written by the R pass for every voxel), so a neighbour costs one gather.  ghost_done[g] is set
 // when helper g turns its ghost leaf on v into a real one (only the thread of v writes it).

@@ -81,6 +81,10 @@ hipError_t launch_fn(uint32_t gx, uint32_t nf, uint32_t lds, hipStream_t st, con
 }
 struct Cmd { LaunchFn fn; uint32_t gx, lds, bytes, off; };
 
+// dirty-tile sweeps: a sweep that changed at most V >> shift voxels lets the next one skip clean tiles.
+// F3DS_INC_SHIFT=-1 turns the skipping off (every sweep evaluates every voxel), 32 forces it always.
+const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e ? atoi(e) : 6; }();
+
 }  // namespace
 
 struct f3ds_ctx {
@@ -118,7 +122,7 @@ struct f3ds_ctx {
     Buf owner0, owner1, ownR, dist0, dist1, R, hc, hcount, hlo, hhi, ghost_vox, ghost_active, ghost_done, ghost_head, ghost_next;
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
-    Buf glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
+    Buf tstamp, tround, hdirty, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
@@ -340,12 +344,18 @@ int seg_seeds(f3ds_ctx* c) {
 int seg_sweeps(f3ds_ctx* c) {
     const uint32_t V = c->V, S0 = c->S0;
     const f3ds_params& prm = c->prm;
-    uint32_t *owner0, *owner1, *ownR, *hcount, *hlo, *hhi, *ghost_head, *ghost_next; float *dist0, *dist1, *hc; unsigned char *R, *ghost_active, *ghost_done; int* ghost_vox;
-    ENSURE(c->owner0, uint32_t, V, owner0); ENSURE(c->owner1, uint32_t, V, owner1); ENSURE(c->ownR, uint32_t, V, ownR); ENSURE(c->dist0, float, V, dist0); ENSURE(c->dist1, float, V, dist1);
+    uint32_t *owner0, *ownR, *hcount, *hlo, *hhi, *ghost_head, *ghost_next; float *dist0, *hc; unsigned char *R, *ghost_active, *ghost_done; int* ghost_vox;
+    ENSURE(c->owner0, uint32_t, V, owner0); ENSURE(c->ownR, uint32_t, V, ownR); ENSURE(c->dist0, float, V, dist0);
     ENSURE(c->R, unsigned char, V, R); ENSURE(c->hc, float, (size_t)(S0 + 1) * 12, hc); ENSURE(c->hcount, uint32_t, S0 + 1, hcount);
     ENSURE(c->hlo, uint32_t, S0 + 1, hlo); ENSURE(c->hhi, uint32_t, S0 + 1, hhi); ENSURE(c->ghost_vox, int, S0 + 1, ghost_vox);
     ENSURE(c->ghost_active, unsigned char, S0 + 1, ghost_active); ENSURE(c->ghost_done, unsigned char, S0 + 1, ghost_done);
     ENSURE(c->ghost_head, uint32_t, V, ghost_head); ENSURE(c->ghost_next, uint32_t, S0 + 1, ghost_next);
+    const uint32_t T = (V + 63u) / 64u;
+    uint32_t *tiles4, *trr, *hD;
+    ENSURE(c->tstamp, uint32_t, (size_t)4 * T, tiles4); ENSURE(c->tround, uint32_t, (size_t)(F3DS_R_ROUNDS - 1) * T, trr); ENSURE(c->hdirty, uint32_t, S0 + 1, hD);
+    rec_fill(c, tiles4, 0u, (size_t)4 * T * 4);
+    rec_fill(c, trr, 0u, (size_t)(F3DS_R_ROUNDS - 1) * T * 4);
+    rec_fill(c, hD, 0u, (size_t)(S0 + 1) * 4);
     rec_fill(c, owner0, 0u, (size_t)V * 4);
     rec_fill(c, ghost_head, 0u, (size_t)V * 4);
     rec_fill(c, ghost_next, 0u, (size_t)(S0 + 1) * 4);
@@ -353,19 +363,20 @@ int seg_sweeps(f3ds_ctx* c) {
     rec<d_helper_own>(c, grid_for(S0, 256), 0u, (const int*)c->seed_kept.p, S0, owner0);
     rec<d_helper_init>(c, grid_for(S0 + 1, 256), 0u, (const int*)c->seed_kept.p, S0, (const uint32_t*)owner0, ghost_vox, ghost_active, ghost_done, hlo, hhi, hcount, hc);
     const int* nbrT = (const int*)c->nbrT.p; const float* vf = (const float*)c->vf.p;
+    SweepFrame a;
+    a.sv = SweepView{(int)V, nbrT, vf, owner0, dist0, hc, ghost_head, ghost_next, (const uint32_t*)&c->d_dc->n_ghosts, prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
+    a.R = R; a.ownR = ownR; a.owner_out = owner0; a.dist_out = dist0;
+    a.ghost_done = ghost_done; a.ghost_active = ghost_active; a.ghost_vox = ghost_vox; a.ghost_head = ghost_head; a.ghost_next = ghost_next;
+    a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
+    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T;
+    a.thr = g_inc_shift >= 32 ? 0xFFFFFFFFu : (g_inc_shift < 0 ? 0u : V >> g_inc_shift);
     for (uint32_t t = 0; t < c->res.sweeps; ++t) {
-        SweepFrame a;
-        a.sv = SweepView{(int)V, nbrT, vf, owner0, dist0, hc, ghost_head, ghost_next, (const uint32_t*)&c->d_dc->n_ghosts, prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
-        a.R = R; a.ownR = ownR; a.owner_out = owner1; a.dist_out = dist1;
-        a.ghost_done = ghost_done; a.ghost_active = ghost_active; a.ghost_vox = ghost_vox; a.ghost_head = ghost_head; a.ghost_next = ghost_next;
-        a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
         if (a_sweep_needs_clear(t)) rec_fill(c, R, 0u, V);
-        rec<d_ghost_relink>(c, 1u, 0u, a);
-        rec<d_sweep_R>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t));
-        rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a);
-        rec<d_centroid>(c, S0 ? S0 : 1u, 0u, a);
-        std::swap(owner0, owner1); std::swap(dist0, dist1);
-        std::swap(c->owner0, c->owner1); std::swap(c->dist0, c->dist1);
+        rec<d_sweep_begin>(c, 1u, 0u, a, t);
+        if (g_inc_shift >= 0) for (uint32_t r = 0; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
+        rec<d_sweep_R>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t);
+        rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
+        rec<d_centroid>(c, (S0 + 3u) / 4u + (S0 ? 0u : 1u), 0u, a, t);
     }
     return F3DS_OK;
 }

@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <set>
@@ -234,43 +236,121 @@ int stage_sweeps(f3ds_emul& E) {
     int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
     E.res.sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0u;
     std::vector<unsigned char> R(V), done(S0 + 1);
-    std::vector<uint32_t> owner2(V), ghost_head(V, 0u), ghost_next(S0 + 1, 0u), ownR(V);
+    std::vector<uint32_t> ghost_head(V, 0u), ghost_next(S0 + 1, 0u), ownR(V, 0u);
     std::vector<int> nbrT((size_t)V * 27);
     for (int v = 0; v < V; ++v) for (int k = 0; k < 27; ++k) nbrT[(size_t)k * V + v] = E.nbr[(size_t)v * 27 + k];
-    std::vector<float> dist2(V);
+    // dirty-tile bookkeeping, the same events and stamps as the device kernels (f3ds_kernels.inc, SweepFrame)
+    const char* env = getenv("F3DS_EMUL_INC_SHIFT");
+    const int shift = env ? atoi(env) : 6;
+    const uint32_t T = (uint32_t)(V + 63) / 64u;
+    const uint32_t thr = shift >= 32 ? 0xFFFFFFFFu : (shift < 0 ? 0u : (uint32_t)V >> shift);
+    const int ROUNDS = 4;
+    std::vector<uint32_t> tR[2] = {std::vector<uint32_t>(T, 0u), std::vector<uint32_t>(T, 0u)}, tC[2] = {std::vector<uint32_t>(T, 0u), std::vector<uint32_t>(T, 0u)};
+    std::vector<std::vector<uint32_t>> tRr(ROUNDS, std::vector<uint32_t>(T, 0u));
+    std::vector<uint32_t> hD(S0 + 1, 0u);
+    uint32_t n_changed = 0, sweep_full = 0, sweep_marks = 0;
+    long stat_inc_sweeps = 0, stat_fallbacks = 0, stat_r_evals = 0, stat_c_evals = 0, stat_h_evals = 0;
+    auto mark = [&](int v, std::vector<uint32_t>& a, std::vector<uint32_t>& b, uint32_t stamp) {
+        for (int k = 0; k < 27; ++k) { int u = nbrT[(size_t)k * V + v]; if (u >= 0) { a[u >> 6] = stamp; b[u >> 6] = stamp; } }
+    };
     for (uint32_t t = 0; t < E.res.sweeps; ++t) {
         for (int h = 1; h <= S0; ++h) if (E.ghost_vox[h] >= 0) ghost_head[E.ghost_vox[h]] = 0u;
         for (int h = 1; h <= S0; ++h) if (E.ghost_active[h]) { ghost_next[h] = ghost_head[E.ghost_vox[h]]; ghost_head[E.ghost_vox[h]] = (uint32_t)h; }
         uint32_t n_ghosts = 0;
         for (int h = 1; h <= S0; ++h) n_ghosts += E.ghost_active[h];
+        if (n_ghosts != 0u || t == 0u || n_changed > thr || sweep_marks != t) sweep_full = t + 1u;
+        if (t != 0u && (thr >= 0x40000000u || n_changed <= 4u * thr)) sweep_marks = t + 1u;
+        n_changed = 0;
         SweepView s{V, nbrT.data(), E.vf.data(), E.owner.data(), E.dist.data(), E.hc.data(), ghost_head.data(), ghost_next.data(), &n_ghosts,
                     prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
-        int overflow = 0;
-        const unsigned char tag = a_sweep_tag(t);
-        if (a_sweep_needs_clear(t)) std::fill(R.begin(), R.end(), (unsigned char)0);
-        for (int v = 0; v < V; ++v) { bool r = E.owner[v] ? a_eval_R(s, v, R.data(), tag, &overflow) : false; ownR[v] = E.owner[v] | (r ? F3DS_OWNR_RTRUE : 0u); }
-        if (overflow) return F3DS_ERR_UNSUPPORTED;
+        const uint32_t stamp = t + 1u;
+        // incremental R rounds (Jacobi: every round reads the ownR of the round before, the least favourable interleaving)
+        if (shift >= 0 && sweep_full != stamp) {
+            stat_inc_sweeps++;
+            for (int r = 0; r < ROUNDS && sweep_full != stamp; ++r) {
+                const std::vector<uint32_t>& cur = r == 0 ? tR[t & 1u] : tRr[r - 1];
+                const bool last = r + 1 == ROUNDS;
+                std::vector<uint32_t> snap = ownR;
+                std::vector<std::pair<int, uint32_t>> writes;
+                for (int v = 0; v < V; ++v) {
+                    if (cur[v >> 6] != stamp) continue;
+                    stat_r_evals++;
+                    const uint32_t nw = E.owner[v] | (a_eval_R_step(s, snap.data(), v) ? F3DS_OWNR_RTRUE : 0u);
+                    if (nw != snap[v]) writes.push_back({v, nw});
+                }
+                for (auto& w : writes) {
+                    ownR[w.first] = w.second;
+                    mark(w.first, last ? tC[t & 1u] : tRr[r], tC[t & 1u], stamp);
+                    if (last) sweep_full = stamp;
+                }
+            }
+            if (sweep_full == stamp) stat_fallbacks++;
+        }
+        if (sweep_full == stamp) {
+            int overflow = 0;
+            const unsigned char tag = a_sweep_tag(t);
+            std::fill(R.begin(), R.end(), (unsigned char)0);
+            for (int v = 0; v < V; ++v) { bool r = E.owner[v] ? a_eval_R(s, v, R.data(), tag, &overflow) : false; ownR[v] = E.owner[v] | (r ? F3DS_OWNR_RTRUE : 0u); }
+            if (overflow) return F3DS_ERR_UNSUPPORTED;
+        }
+        // claim, in place
         std::fill(done.begin(), done.end(), 0);
-        for (int v = 0; v < V; ++v) a_claim(s, ownR.data(), v, &owner2[v], &dist2[v], done.data());
-        E.owner.swap(owner2); E.dist.swap(dist2);
-        for (int h = 1; h <= S0; ++h) if (done[h]) E.ghost_active[h] = 0;
-        std::vector<float> sum((size_t)(S0 + 1) * 9, 0.0f);
-        std::fill(E.hcount.begin(), E.hcount.end(), 0u);
+        {
+            const bool full = sweep_full == stamp;
+            std::vector<std::pair<int, std::pair<uint32_t, float>>> writes;
+            for (int v = 0; v < V; ++v) {
+                if (!full && tC[t & 1u][v >> 6] != stamp) continue;
+                stat_c_evals++;
+                uint32_t o; float d;
+                a_claim(s, ownR.data(), v, &o, &d, done.data());
+                uint32_t db, d0b; memcpy(&db, &d, 4); memcpy(&d0b, &E.dist[v], 4);
+                if (o != E.owner[v] || db != d0b) writes.push_back({v, {o, d}});
+            }
+            for (auto& w : writes) {
+                const int v = w.first; const uint32_t o0 = E.owner[v], o = w.second.first;
+                E.owner[v] = o; E.dist[v] = w.second.second;
+                if (o != o0) { if (o) hD[o] = stamp; if (o0) hD[o0] = stamp; }
+                if (sweep_marks == stamp) mark(v, tR[(t + 1u) & 1u], tC[(t + 1u) & 1u], t + 2u);
+                n_changed++;
+            }
+        }
+        if (getenv("F3DS_EMUL_SWEEP_STATS")) {
+            static long pr = 0, pc = 0;
+            fprintf(stderr, "sweep %u: changed %u ghosts %u full %d  R evals %ld claim evals %ld\n", t, n_changed, n_ghosts, sweep_full == stamp, stat_r_evals - pr, stat_c_evals - pc);
+            pr = stat_r_evals; pc = stat_c_evals;
+        }
+        // updateCentroid of the helpers whose leaf set changed
+        const bool marks = n_changed <= thr && sweep_marks == stamp;
         std::map<int, std::vector<int>> gmap;
-        for (int h = 1; h <= S0; ++h) if (E.ghost_active[h]) gmap[E.ghost_vox[h]].push_back(h);
+        for (int h = 1; h <= S0; ++h) if (E.ghost_active[h] && !done[h]) gmap[E.ghost_vox[h]].push_back(h);
+        std::vector<unsigned char> proc(S0 + 1, 0);
+        for (int h = 1; h <= S0; ++h) proc[h] = !(t != 0u && hD[h] != stamp && !E.ghost_active[h]);
+        std::vector<float> sum((size_t)(S0 + 1) * 9, 0.0f);
+        std::vector<uint32_t> cnt(S0 + 1, 0u);
         auto add = [&](uint32_t h, int v) {
+            if (!proc[h]) return;
             const float* f = &E.vf[(size_t)v * 12];
             float* q = &sum[(size_t)h * 9];
             for (int k = 0; k < 9; ++k) q[k] += f[k];
-            E.hcount[h]++;
+            cnt[h]++;
+            if (marks) mark(v, tR[(t + 1u) & 1u], tC[(t + 1u) & 1u], t + 2u);
         };
         for (int v = 0; v < V; ++v) {       // ascending ordinal = SupervoxelHelper leaf order
             uint32_t h = E.owner[v];
             if (h) add(h, v);
             if (!gmap.empty()) { auto it = gmap.find(v); if (it != gmap.end()) for (int g : it->second) add((uint32_t)g, v); }
         }
-        for (int h = 1; h <= S0; ++h) if (E.hcount[h]) a_centroid_finish(&sum[(size_t)h * 9], E.hcount[h], &E.hc[(size_t)h * 12]);
+        for (int h = 1; h <= S0; ++h) {
+            if (!proc[h]) continue;
+            stat_h_evals++;
+            if (done[h]) E.ghost_active[h] = 0;
+            E.hcount[h] = cnt[h];
+            if (cnt[h]) a_centroid_finish(&sum[(size_t)h * 9], cnt[h], &E.hc[(size_t)h * 12]);
+        }
     }
+    if (getenv("F3DS_EMUL_SWEEP_STATS"))
+        fprintf(stderr, "incremental sweeps %ld of %u, fallbacks %ld, R evals %ld, claim evals %ld, centroid evals %ld (full would be %ld / %ld / %ld)\n", stat_inc_sweeps,
+                E.res.sweeps, stat_fallbacks, stat_r_evals, stat_c_evals, stat_h_evals, (long)V * E.res.sweeps, (long)V * E.res.sweeps, (long)S0 * E.res.sweeps);
     return 0;
 }
 

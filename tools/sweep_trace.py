@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Per-sweep durations (us) of the sweep kernels of the last batched dispatch sequence in a rocprofv3 kernel trace.
+usage: tools/sweep_trace.py <dir> <frames per batch>"""
+import csv, glob, re, collections, sys
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
+nf = sys.argv[2]
+seq = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    m = re.search(r"d_([A-Za-z_0-9]+)", r["Kernel_Name"])
+    if not m or r["Grid_Size_Y"] != nf:
+        continue
+    seq[m.group(0)].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+for n in ("d_sweep_begin", "d_sweep_R_round", "d_sweep_R", "d_sweep_claim", "d_centroid"):
+    v = sorted(seq.get(n, []))
+    if not v:
+        continue
+    per = 64 if n == "d_sweep_R_round" else 16
+    last = [round(x[1]) for x in v[-per:]]
+    print("%-16s sum %6d us  %s" % (n, sum(last), last))
