@@ -299,7 +299,7 @@ int seg_voxels(f3ds_ctx* c) {
                        (const GridInfo*)c->d_grid, vkey, vcount, vf, (int*)c->pt_voxel.p, hkeys, hvals, c->hmask);
     rec<d_neighbors>(c, grid_for((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                      c->hmask, nbr, nbrT);
-    rec<d_normals>(c, (V + NT_THREADS - 1) / NT_THREADS, 0u, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
+    rec<d_normals>(c, (V + NT_TILE - 1) / NT_TILE, 0u, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
     const uint32_t nchunks = (V + SEED_CHUNK - 1) / SEED_CHUNK;
     ENSURE(c->boxes, float, (size_t)nchunks * 6, boxes);
     rec<d_chunkbox>(c, nchunks, 0u, (const float*)vf, (const DevCounters*)c->d_dc, boxes);
