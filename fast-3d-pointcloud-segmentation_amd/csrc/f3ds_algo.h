@@ -225,11 +225,13 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
     const float dw = s.dist[w];
     // neighbours owned by a lower label (the only possible thieves before h's turn); every lane of a
     // wave first collects them, then the expensive distance is evaluated once per distinct owner
+    // (loads are unconditional -- an absent neighbour reads w's own entry -- so that the 27 index loads and
+    // then the 27 gathers are each in flight together instead of one round trip per neighbour)
     int nu[27]; uint32_t og[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
     for (int k = 0; k < 27; ++k) {
-        const int u = a_nbr(s, w, k);
-        const uint32_t g = u >= 0 ? s.owner[u] : 0u;
-        nu[k] = u; og[k] = (g != 0u && g < h) ? g : 0u;
+        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];
+        og[k] = (nu[k] >= 0 && g != 0u && g < h) ? g : 0u;
     }
     bool stolen = false, unknown = false;
     uint32_t last = 0;
@@ -260,12 +262,12 @@ F3DS_HD bool a_eval_R_step(const SweepView& s, const uint32_t* ownR, int w) {
     const uint32_t h = s.owner[w];
     if (h == 0u) return false;
     const float dw = s.dist[w];
-    uint32_t og[27];
+    int nu[27]; uint32_t og[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
     for (int k = 0; k < 27; ++k) {
-        const int u = a_nbr(s, w, k);
-        uint32_t g = 0u;
-        if (u >= 0) { g = s.owner[u]; if (!(g != 0u && g < h && (ownR[u] & F3DS_OWNR_RTRUE))) g = 0u; }
-        og[k] = g;       // lower helper that still holds u at its turn (as far as ownR knows)
+        const int u = nu[k] >= 0 ? nu[k] : w;        // unconditional loads, see a_eval_R
+        const uint32_t g = s.owner[u], x = ownR[u];
+        og[k] = (nu[k] >= 0 && g != 0u && g < h && (x & F3DS_OWNR_RTRUE)) ? g : 0u;       // lower helper that still holds u at its turn (as far as ownR knows)
     }
     uint32_t last = 0;
     for (;;) {
@@ -283,11 +285,11 @@ F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* 
     const bool ghosts = *s.n_ghosts != 0u;
     uint32_t o = s.owner[v];
     float d = s.dist[v];
-    uint32_t cand[27];
+    int nu[27]; uint32_t cand[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, v, k);
     for (int k = 0; k < 27; ++k) {
-        const int u = a_nbr(s, v, k);
-        const uint32_t x = u >= 0 ? ownR[u] : 0u;
-        cand[k] = (x & F3DS_OWNR_RTRUE) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
+        const uint32_t x = ownR[nu[k] >= 0 ? nu[k] : v];               // unconditional loads, see a_eval_R
+        cand[k] = (nu[k] >= 0 && (x & F3DS_OWNR_RTRUE)) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
     }
     uint32_t last = 0;
     for (;;) {

@@ -401,8 +401,8 @@ int seg_supervoxels(f3ds_ctx* c) {
     ENSURE(c->ehk, uint64_t, ehcap, ehk);
     ENSURE(c->ekeys0, uint64_t, ecap, ek0); ENSURE(c->ekeys1, uint64_t, ecap, ek1); ENSURE(c->evals0, uint32_t, ecap, ev0); ENSURE(c->evals1, uint32_t, ecap, ev1);
     rec_fill(c, ehk, 0xFFFFFFFFu, (size_t)ehcap * 8);
-    rec<d_edges>(c, grid_for(V, 256), 0u, V, S0, (const int*)c->nbr.p, (const uint32_t*)c->owner0.p, ehk, ehcap - 1, ek0, ecap, c->d_dc);
-    rec<d_edges_ghost>(c, grid_for(S0, 256), 0u, S0, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p, (const int*)c->nbr.p, (const uint32_t*)c->owner0.p, ehk,
+    rec<d_edges>(c, grid_for(V, 256), 0u, V, S0, (const int*)c->nbrT.p, (const uint32_t*)c->owner0.p, ehk, ehcap - 1, ek0, ecap, c->d_dc);
+    rec<d_edges_ghost>(c, grid_for(S0, 256), 0u, V, S0, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p, (const int*)c->nbrT.p, (const uint32_t*)c->owner0.p, ehk,
                        ehcap - 1, ek0, ecap, c->d_dc);
     return F3DS_OK;
 }
