@@ -44,7 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 STAGES = ["voxelise", "neighbours+normals", "seeds", "sweeps", "summaries+adjacency+weights", "merge", "labels"]
 # the kernel that dominates each stage (rocprofv3 --kernel-trace names in profiles/)
-STAGE_KERNEL = {"voxelise": "k_batched<d_radix_scatter>", "neighbours+normals": "k_batched<d_normals>", "seeds": "k_batched<d_seed_nn>", "sweeps": "k_batched<d_sweep_claim>",
+STAGE_KERNEL = {"voxelise": "k_batched<d_radix_scatter>", "neighbours+normals": "k_batched<d_normals>", "seeds": "k_batched<d_seed_nn>", "sweeps": "k_batched<d_sweep_R>",
                 "summaries+adjacency+weights": "k_batched<d_sv_fill>", "merge": "k_batched<d_merge_lds>", "labels": "k_batched<d_point_labels>"}
 ALG_BYTES_PER_POINT = 20          # 16 B read of {x,y,z,rgba} + 4 B label write
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
@@ -53,9 +53,9 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1152)
-    ap.add_argument("--warmup", type=int, default=288)
-    ap.add_argument("--batch", type=int, default=96, help="frames per f3ds_segment_batch call")
+    ap.add_argument("--steps", type=int, default=2304)
+    ap.add_argument("--warmup", type=int, default=576)
+    ap.add_argument("--batch", type=int, default=192, help="frames per f3ds_segment_batch call")
     ap.add_argument("--groups", type=int, default=3, help="batch calls in flight per GPU")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames to cycle through")
     ap.add_argument("--width", type=int, default=1000)

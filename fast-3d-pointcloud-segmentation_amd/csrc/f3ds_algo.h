@@ -145,8 +145,23 @@ struct SweepView {
     float seed_res, w_normal, w_color, w_spatial;
 };
 F3DS_HD int a_nbr(const SweepView& s, int v, int k) { return s.nbrT[(size_t)k * (size_t)s.V + (size_t)v]; }
+// feature rows are 48 bytes, 16-byte aligned: three 128-bit loads instead of nine 32-bit ones
+F3DS_HD void a_load_row(const float* p, float out[12]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1], c = reinterpret_cast<const float4*>(p)[2];
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w; out[8] = c.x; out[9] = c.y; out[10] = c.z; out[11] = c.w;
+#else
+    for (int k = 0; k < 12; ++k) out[k] = p[k];
+#endif
+}
 F3DS_HD float a_helper_dist(const SweepView& s, uint32_t g, int v) {
     return n_voxel_distance(s.hc + (size_t)g * 12, s.vf + (size_t)v * 12, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
+}
+// the same with the voxel's row already loaded (the sweep kernels test one voxel against several helpers)
+F3DS_HD float a_helper_dist_row(const SweepView& s, uint32_t g, const float vrow[12]) {
+    float hrow[12];
+    a_load_row(s.hc + (size_t)g * 12, hrow);
+    return n_voxel_distance(hrow, vrow, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
 }
 #define F3DS_R_STACK 24
 #define F3DS_R_TRUE 1
@@ -269,13 +284,15 @@ F3DS_HD bool a_eval_R_step(const SweepView& s, const uint32_t* ownR, int w) {
         const uint32_t g = s.owner[u], x = ownR[u];
         og[k] = (nu[k] >= 0 && g != 0u && g < h && (x & F3DS_OWNR_RTRUE)) ? g : 0u;       // lower helper that still holds u at its turn (as far as ownR knows)
     }
+    float wrow[12];
+    a_load_row(s.vf + (size_t)w * 12, wrow);
     uint32_t last = 0;
     for (;;) {
         uint32_t g = 0xFFFFFFFFu;
         for (int k = 0; k < 27; ++k) if (og[k] > last && og[k] < g) g = og[k];
         if (g == 0xFFFFFFFFu) return true;
         last = g;
-        if (a_helper_dist(s, g, w) < dw) return false;
+        if (a_helper_dist_row(s, g, wrow) < dw) return false;
     }
 }
 // state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
@@ -291,6 +308,8 @@ F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* 
         const uint32_t x = ownR[nu[k] >= 0 ? nu[k] : v];               // unconditional loads, see a_eval_R
         cand[k] = (nu[k] >= 0 && (x & F3DS_OWNR_RTRUE)) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
     }
+    float vrow[12];
+    a_load_row(s.vf + (size_t)v * 12, vrow);
     uint32_t last = 0;
     for (;;) {
         uint32_t g = 0xFFFFFFFFu;     // smallest candidate label above `last`
@@ -308,7 +327,7 @@ F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* 
         if (g == 0xFFFFFFFFu) break;
         last = g;
         if (g == o) continue;          // neighbor_voxel.owner_ == this
-        float dg = a_helper_dist(s, g, v);
+        float dg = a_helper_dist_row(s, g, vrow);
         if (dg < d) {
             d = dg; o = g;
             if (ghosts)

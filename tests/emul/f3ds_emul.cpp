@@ -286,6 +286,25 @@ int stage_sweeps(f3ds_emul& E) {
             }
             if (sweep_full == stamp) stat_fallbacks++;
         }
+        if (sweep_full == stamp && getenv("F3DS_EMUL_JACOBI_STATS")) {
+            // experiment: Jacobi rounds of a_eval_R_step from the previous sweep's R bits, all tiles dirty in round 0
+            std::vector<uint32_t> jr = ownR;
+            for (int v = 0; v < V; ++v) jr[v] = E.owner[v] | (t == 0 ? F3DS_OWNR_RTRUE : (jr[v] & F3DS_OWNR_RTRUE));
+            std::vector<unsigned char> dirty(T, 1), nd(T, 0);
+            for (int r = 0; r < 64; ++r) {
+                std::vector<uint32_t> snap = jr; long ev = 0, flips = 0;
+                std::fill(nd.begin(), nd.end(), 0);
+                for (int v = 0; v < V; ++v) {
+                    if (!dirty[v >> 6]) continue;
+                    ev++;
+                    const uint32_t nw = E.owner[v] | (a_eval_R_step(s, snap.data(), v) ? F3DS_OWNR_RTRUE : 0u);
+                    if (nw != snap[v]) { jr[v] = nw; flips++; for (int k = 0; k < 27; ++k) { int u = nbrT[(size_t)k * V + v]; if (u >= 0) nd[u >> 6] = 1; } }
+                }
+                fprintf(stderr, "   sweep %u jacobi round %d: evals %ld flips %ld\n", t, r, ev, flips);
+                if (!flips) break;
+                dirty.swap(nd);
+            }
+        }
         if (sweep_full == stamp) {
             int overflow = 0;
             const unsigned char tag = a_sweep_tag(t);
