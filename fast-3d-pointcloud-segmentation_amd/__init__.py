@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libf3ds.so")
+LIB_PATH = os.environ.get("F3DS_LIB") or os.path.join(_HERE, "libf3ds.so")       # F3DS_LIB: A/B builds during development
 
 NO_LABEL = 0xFFFFFFFF
 LAB_CIEDE00, RGB_EUCL = 0, 1

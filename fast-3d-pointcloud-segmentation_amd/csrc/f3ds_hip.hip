@@ -427,7 +427,7 @@ bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl) {
     memset(xl, 0, sizeof *xl);
     xl->Ecap = (E + 63u) & ~63u; if (!xl->Ecap) xl->Ecap = 64u;
     xl->G = xl->Ecap / 64u;
-    const uint32_t lds_fixed = xl->Ecap * 8u + xl->G * 8u + (2u * ML_THREADS + 1u) * 4u + ((xl->G + 15u) & ~15u);
+    const uint32_t lds_fixed = xl->Ecap * 8u + xl->G * 8u + (2u * ML_THREADS + 1u) * 4u + 4u * ML_TL_CAP * 4u + ((xl->G + 15u) & ~15u);
     xl->stage_off = (lds_fixed + 15u) & ~15u;
     const uint32_t lds_budget = 160u * 1024u - 8192u;     // static LDS of the kernel (scan scratch, dirty list, scalars)
     const bool ok = S0 <= 65534u && xl->stage_off + 128u * 52u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
@@ -468,11 +468,11 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds) {
     merge_fits_lds(E, S0, &xl);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u);
-    ENSURE(c->pool, uint32_t, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
+    ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
     ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
     xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);
     c->merge_in_lds = use_lds;
-    rec<d_region_reset>(c, grid_for(S0 + 1, 256), 0u, S0, (const uint32_t*)c->hcount.p, m.rhead, m.rtail, m.lnext, m.parent, m.markA, m.markB, xl.pool, xl.rstart, xl.rnleaf, xl.rcap);
+    rec<d_region_reset>(c, grid_for(S0 + 1, 256), 0u, S0, (const uint32_t*)c->hcount.p, m.rhead, m.rtail, m.lnext, m.parent, m.markA, m.markB, xl.pool, xl.rstart, xl.rnleaf, xl.rcap, (const uint32_t*)c->loff.p);
     m.mp.color_metric = prm->color_metric; m.mp.geom_metric = prm->geom_metric; m.mp.merging = prm->merging; m.mp.lambda = lambda; m.mp.bins = bins;
     uint64_t *sk0 = nullptr, *sk1 = nullptr; uint32_t *sv0 = nullptr, *sv1 = nullptr;
     if (prm->merging == F3DS_ADAPTIVE_LAMBDA) {
@@ -538,8 +538,8 @@ int for_frames(Batch& b, F&& fn) {
 void stage_mark(Batch& b, int i) { (void)hipEventRecord(b.owner->ev[i], b.st); }
 
 // cluster stage for the live frames (also the whole of f3ds_recluster)
-int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, const std::vector<int>& index_of, int labels_on_device) {
-    bool all_lds = true;
+int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, const std::vector<int>& index_of, int labels_on_device, bool force_global = false) {
+    bool all_lds = !force_global;
     for (f3ds_ctx* c : b.fr) { MergeLds t; if (!merge_fits_lds(c->E, c->S0, &t)) all_lds = false; }
     int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, all_lds); });
     if (rc || (rc = flush(b))) return rc;
@@ -554,6 +554,16 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         if (out) HIPCHECK(hipMemcpyAsync(out, c->labels.p, (size_t)c->n * 4, labels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, b.st));
     }
     if ((rc = flush_sync(b))) return rc;
+    if (all_lds) {
+        // a merge whose two regions touch more than ML_TL_CAP edges does not fit the LDS kernel's lists: the stage
+        // (it starts from the untouched supervoxel state) runs again with the global-memory kernel
+        bool again = false;
+        for (f3ds_ctx* c : b.fr) if (c->h_dc->error == F3DS_ERR_UNSUPPORTED) again = true;
+        if (again) {
+            for (f3ds_ctx* c : b.fr) { c->h_dc->error = 0; HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); }
+            return run_cluster(b, prm, labels_of, index_of, labels_on_device, true);
+        }
+    }
     for (f3ds_ctx* c : b.fr) {
         if (c->h_dc->error) return c->h_dc->error;
         c->res.n_merges = c->h_dc->n_merges; c->res.n_regions = c->h_dc->n_regions;
@@ -771,23 +781,23 @@ extern "C" int f3ds_get_voxel_cloud(f3ds_ctx* c, float* xyz, uint32_t* label, ui
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     const uint32_t S0 = c->S0;
-    std::vector<unsigned char> ralive; std::vector<uint32_t> rhead, lnext, loff, llen, pool, rstart, rnleaf; std::vector<float> rows;
+    std::vector<unsigned char> ralive; std::vector<uint32_t> rhead, lnext, loff, llen, rstart, rnleaf; std::vector<uint2> pool; std::vector<float> rows;
     int rc;
     if ((rc = fetch(c, c->ralive, S0 + 1, ralive)) || (rc = fetch(c, c->rhead, S0 + 1, rhead)) || (rc = fetch(c, c->lnext, S0 + 1, lnext)) ||
         (rc = fetch(c, c->loff, S0 + 2, loff)) || (rc = fetch(c, c->hcount, S0 + 1, llen)))
         return rc;
-    if (c->merge_in_lds && ((rc = fetch(c, c->pool, c->pool.cap / 4, pool)) || (rc = fetch(c, c->rstart, S0 + 1, rstart)) || (rc = fetch(c, c->rnleaf, S0 + 1, rnleaf)))) return rc;
+    if (c->merge_in_lds && ((rc = fetch(c, c->pool, c->pool.cap / 8, pool)) || (rc = fetch(c, c->rstart, S0 + 1, rstart)) || (rc = fetch(c, c->rnleaf, S0 + 1, rnleaf)))) return rc;
     if ((rc = fetch(c, c->rows, (size_t)loff[S0 + 1] * 12, rows))) return rc;
     size_t k = 0; uint32_t cur = 0;
     for (uint32_t h = 1; h <= S0; ++h) {
         if (!ralive[h]) continue;
-        std::vector<uint32_t> leaves;      // the region's leaves in voxels_ concatenation order
+        std::vector<uint2> leaves;      // the region's leaves (first payload row, rows) in voxels_ concatenation order
         if (c->merge_in_lds) leaves.assign(pool.begin() + rstart[h], pool.begin() + rstart[h] + rnleaf[h]);
-        else for (uint32_t leaf = rhead[h]; leaf; leaf = lnext[leaf]) leaves.push_back(leaf);
-        for (uint32_t leaf : leaves)
-            for (uint32_t j = 0; j < llen[leaf]; ++j) {
+        else for (uint32_t leaf = rhead[h]; leaf; leaf = lnext[leaf]) leaves.push_back(make_uint2(loff[leaf], llen[leaf]));
+        for (const uint2& leaf : leaves)
+            for (uint32_t j = 0; j < leaf.y; ++j) {
                 if (k < cap) {
-                    const float* r = &rows[(size_t)(loff[leaf] + j) * 12];
+                    const float* r = &rows[(size_t)(leaf.x + j) * 12];
                     if (xyz) { xyz[3 * k] = r[6]; xyz[3 * k + 1] = r[7]; xyz[3 * k + 2] = r[8]; }
                     if (label) label[k] = cur;
                     if (rgba) rgba[k] = f3ds_glasbey_256[cur % 256u];
