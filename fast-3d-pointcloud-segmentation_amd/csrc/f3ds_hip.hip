@@ -102,6 +102,7 @@ struct f3ds_ctx {
     std::vector<unsigned char> blob;
     // pinned + device staging for the packed arguments of a batch (owned by the batch's first context)
     unsigned char* h_args = nullptr; unsigned char* d_args = nullptr; size_t args_cap = 0;
+    DevCounters* d_dcblk = nullptr; DevCounters* h_dcblk = nullptr; size_t dcblk_cap = 0;      // the batch's counters, one slot per frame
     // frame state
     bool have_frame = false;
     bool live = false;
@@ -115,6 +116,7 @@ struct f3ds_ctx {
     uint64_t *eks = nullptr;                             // sorted edge keys
     f3ds_result res;
     bool merge_in_lds = false;
+    uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
     // device scratch (grow-only)
     Buf pts, keys0, keys1, vals0, vals1, flags, incl, tiles, hist, seg_start, pt_voxel, labels;
@@ -222,9 +224,26 @@ int flush(Batch& b) {
 int flush_sync(Batch& b) {
     int rc = flush(b);
     if (rc) return rc;
-    for (f3ds_ctx* c : b.fr) HIPCHECK(hipMemcpyAsync(c->h_dc, c->d_dc, sizeof(DevCounters), hipMemcpyDeviceToHost, b.st));
+    const size_t nf = b.fr.size();
+    if (nf == 1) HIPCHECK(hipMemcpyAsync(b.fr[0]->h_dc, b.fr[0]->d_dc, sizeof(DevCounters), hipMemcpyDeviceToHost, b.st));
+    else if (nf > 1) {
+        // one gather kernel + one copy instead of a copy per frame
+        f3ds_ctx* o = b.owner;
+        if (o->dcblk_cap < nf) {
+            HIPCHECK(hipStreamSynchronize(b.st));
+            if (o->d_dcblk) HIPCHECK(hipFree(o->d_dcblk));
+            if (o->h_dcblk) HIPCHECK(hipHostFree(o->h_dcblk));
+            o->dcblk_cap = nf * 2;
+            HIPCHECK(hipMalloc((void**)&o->d_dcblk, o->dcblk_cap * sizeof(DevCounters)));
+            HIPCHECK(hipHostMalloc((void**)&o->h_dcblk, o->dcblk_cap * sizeof(DevCounters), hipHostMallocDefault));
+        }
+        for (size_t i = 0; i < nf; ++i) rec<d_dc_gather>(b.fr[i], 1u, 0u, (const DevCounters*)b.fr[i]->d_dc, o->d_dcblk + i);
+        if ((rc = flush(b))) return rc;
+        HIPCHECK(hipMemcpyAsync(o->h_dcblk, o->d_dcblk, nf * sizeof(DevCounters), hipMemcpyDeviceToHost, b.st));
+    }
     HIPCHECK(hipStreamSynchronize(b.st));
     HIPCHECK(hipGetLastError());
+    if (nf > 1) for (size_t i = 0; i < nf; ++i) *b.fr[i]->h_dc = b.owner->h_dcblk[i];
     return F3DS_OK;
 }
 
@@ -509,7 +528,8 @@ int seg_labels(f3ds_ctx* c) {
     const MergeDev& m = c->mdev;
     uint32_t *root, *rflags, *rincl, *d_labels;
     ENSURE(c->root, uint32_t, S0 + 1, root); ENSURE(c->rflags, uint32_t, S0 + 1, rflags); ENSURE(c->rincl, uint32_t, S0 + 1, rincl);
-    ENSURE(c->labels, uint32_t, n, d_labels);
+    if (c->user_labels) d_labels = c->user_labels;      // a device output buffer is written in place
+    else ENSURE(c->labels, uint32_t, n, d_labels);
     rec<d_roots>(c, grid_for(S0 + 1, 256), 0u, S0, (const uint32_t*)m.parent, (const unsigned char*)m.ralive, root, rflags);
     int rc = scan_u32(c, rflags, rincl, S0 + 1);
     if (rc) return rc;
@@ -546,12 +566,14 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     stage_mark(b, 5);
     if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
     stage_mark(b, 6);
+    for (size_t i = 0; i < b.fr.size(); ++i) b.fr[i]->user_labels = (labels_on_device && labels_of) ? labels_of[index_of[i]] : nullptr;
     if ((rc = for_frames(b, seg_labels)) || (rc = flush(b))) return rc;
     stage_mark(b, 7);
     for (size_t i = 0; i < b.fr.size(); ++i) {
         f3ds_ctx* c = b.fr[i];
         uint32_t* out = labels_of ? labels_of[index_of[i]] : nullptr;
-        if (out) HIPCHECK(hipMemcpyAsync(out, c->labels.p, (size_t)c->n * 4, labels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, b.st));
+        if (out && !c->user_labels) HIPCHECK(hipMemcpyAsync(out, c->labels.p, (size_t)c->n * 4, hipMemcpyDeviceToHost, b.st));
+        c->user_labels = nullptr;
     }
     if ((rc = flush_sync(b))) return rc;
     if (all_lds) {
@@ -623,6 +645,8 @@ void f3ds_destroy(f3ds_ctx* c) {
     if (c->h_grid) (void)hipHostFree(c->h_grid);
     if (c->d_sgrid) (void)hipFree(c->d_sgrid);
     if (c->h_args) (void)hipHostFree(c->h_args);
+    if (c->d_dcblk) (void)hipFree(c->d_dcblk);
+    if (c->h_dcblk) (void)hipHostFree(c->h_dcblk);
     if (c->d_args) (void)hipFree(c->d_args);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
