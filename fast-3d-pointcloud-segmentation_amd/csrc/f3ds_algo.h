@@ -295,6 +295,29 @@ F3DS_HD bool a_eval_R_step(const SweepView& s, const uint32_t* ownR, int w) {
         if (a_helper_dist_row(s, g, wrow) < dw) return false;
     }
 }
+// Can any lower helper steal w at all, whatever the R of its leaves?  False means R(w) holds without looking at
+// any other voxel; the full sweeps settle most voxels this way and run the chain walker on the rest only.
+// (Same tests as a_eval_R_step with every neighbour's R taken as true; not for sweeps with ghost leaves.)
+F3DS_HD bool a_has_thief(const SweepView& s, int w) {
+    const uint32_t h = s.owner[w];
+    const float dw = s.dist[w];
+    int nu[27]; uint32_t og[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
+    for (int k = 0; k < 27; ++k) {
+        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];
+        og[k] = (nu[k] >= 0 && g != 0u && g < h) ? g : 0u;
+    }
+    float wrow[12];
+    a_load_row(s.vf + (size_t)w * 12, wrow);
+    uint32_t last = 0;
+    for (;;) {
+        uint32_t g = 0xFFFFFFFFu;
+        for (int k = 0; k < 27; ++k) if (og[k] > last && og[k] < g) g = og[k];
+        if (g == 0xFFFFFFFFu) return false;
+        last = g;
+        if (a_helper_dist_row(s, g, wrow) < dw) return true;
+    }
+}
 // state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
 // (written by the R pass for every voxel), so a neighbour costs one gather.  ghost_done[g] is set
 // when helper g turns its ghost leaf on v into a real one (only the thread of v writes it).
