@@ -219,3 +219,30 @@ def test_cli_automatic_threshold(P, oracle, tmp_path):
     row = open(str(tmp_path / "sweep_fscore.csv")).read().strip().rstrip(";").split(";")
     assert len(row) == len(otable) and [float(x) for x in row] == pytest.approx([s["fscore"] for s in otable.values()], rel=1e-5)
     assert "F-score\t%f" % obp.fscore in r.stdout or obt == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", ["-1", "32", "2"])
+def test_dirty_tile_sweeps_are_bit_identical_at_any_setting(P, shift):
+    """F3DS_INC_SHIFT=-1 never skips a tile, 32 always tries to (falling back to the chain walker when the R rounds do
+    not converge), 2 switches early: the sweep results must not depend on it.  The library reads the variable when
+    it is loaded, hence the child process."""
+    import hashlib, json, subprocess, sys
+    names = ["rgbd_320x240_ghosts", "rgbd_320x240_large_supervoxels", "fixture_launch_flags"]
+    code = (
+        "import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import conftest; from golden_cases import case_points, case_params\n"
+        "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
+        "for n in %r:\n"
+        "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
+        "    out[n] = dict(labels=hashlib.sha256(lab.tobytes()).hexdigest(), **{w: hashlib.sha256(ctx.debug(w).tobytes()).hexdigest() for w in ('VOXEL_SVLABEL', 'VOXEL_DIST', 'SV_CENTROID', 'MERGES')})\n"
+        "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
+    env = dict(os.environ, F3DS_INC_SHIFT=shift)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+    for n in names:
+        assert got[n]["labels"] == gold[n]["labels_sha256"], (n, shift)
+        for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
+            assert got[n][w] == gold[n]["sha256"][w], (n, w, shift)
