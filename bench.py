@@ -80,6 +80,8 @@ def main():
 
     P = importlib.import_module("fast-3d-pointcloud-segmentation_amd")
     prm = P.launch_params(voxel_res=0.008, seed_res=0.08)          # -v 0.008 -s 0.08 --AL --CVX -t 0.2
+    if os.environ.get("F3DS_BENCH_THRESHOLD"):                    # development only: what-if runs (the JSON line then names the threshold)
+        prm.threshold = float(os.environ["F3DS_BENCH_THRESHOLD"])
     npts = args.width * args.height
 
     # synthetic frames -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
@@ -203,7 +205,7 @@ def main():
         line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t 0.2" % (args.width, args.height, npts),
+                "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t %g" % (args.width, args.height, npts, prm.threshold),
                            "frames_in_flight_per_gpu": nstreams, "batch": nbatch, "concurrent_batches": ngroups, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
                            "label_gather": "one RCCL gather of the batch's label block (batch x 4 MB per rank) to rank 0 per batch" if world > 1 else "none",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
