@@ -443,20 +443,29 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
     return F3DS_OK;
 }
 // fits the LDS-resident merge kernel?
-bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl) {
+bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl, bool keys_global = false) {
     memset(xl, 0, sizeof *xl);
     xl->Ecap = (E + 63u) & ~63u; if (!xl->Ecap) xl->Ecap = 64u;
     xl->G = xl->Ecap / 64u;
-    const uint32_t lds_fixed = xl->Ecap * 8u + xl->G * 8u + (2u * ML_THREADS + 1u) * 4u + 4u * ML_TL_CAP * 4u + ((xl->G + 15u) & ~15u);
-    xl->stage_off = (lds_fixed + 15u) & ~15u;
-    const uint32_t lds_budget = 160u * 1024u - 8192u;     // static LDS of the kernel (scan scratch, dirty list, scalars)
-    const bool ok = S0 <= 65534u && xl->stage_off + 128u * 52u <= lds_budget && !getenv("F3DS_FORCE_GLOBAL_MERGE");
+    const uint32_t lds_budget = 160u * 1024u - 8192u;     // static LDS of the kernel (scan scratch, scalars)
+    const uint32_t lds_rest = xl->G * 8u + (2u * ML_THREADS + 1u) * 4u + 4u * ML_TL_CAP * 4u + ((xl->G + 15u) & ~15u);
+    // order keys in LDS (8 bytes per edge) when that leaves room for at least 128 staged rows, else in global memory
+    // (4 bytes per edge: d_merge_lds_big), else the global-memory kernel
+    bool ok = false;
+    for (int keys_in_lds = keys_global ? 0 : 1; keys_in_lds >= 0 && !ok; --keys_in_lds) {
+        const uint32_t lds_fixed = xl->Ecap * (keys_in_lds ? 8u : 4u) + lds_rest;
+        xl->stage_off = (lds_fixed + 15u) & ~15u;
+        xl->keys_in_lds = keys_in_lds;
+        ok = xl->stage_off + 128u * 52u <= lds_budget;
+    }
+    ok = ok && S0 <= 65534u && !getenv("F3DS_FORCE_GLOBAL_MERGE");
+    if (ok && getenv("F3DS_FORCE_BIG_MERGE") && xl->keys_in_lds) { xl->keys_in_lds = 0; xl->stage_off = (xl->Ecap * 4u + lds_rest + 15u) & ~15u; }     // tests
     xl->caprows = ok ? (lds_budget - xl->stage_off) / 52u : 128u;
     if (xl->caprows > 2048u) xl->caprows = 2048u;
     return ok;
 }
 // stage 4c: Clustering::cluster(threshold) up to the merge loop: working copies, deltas, lambda / cdf, weights
-int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds) {
+int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds, bool keys_global) {
     const uint32_t S0 = c->S0, E = c->E;
     // main(): set_merging / set_lambda / set_bins_num (src/supervoxel_clustering.cpp:415-423)
     float lambda = 0.5f; int bins = 500;
@@ -467,7 +476,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds) {
     memset(&m, 0, sizeof m);
     m.E = E; m.S0 = S0; m.threshold = prm->threshold; m.dc = c->d_dc;
     m.ev_cap = E * 64u + 4096u;
-    ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, E, m.ew); ENSURE(c->eku, uint32_t, E, m.eku);
+    ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, E, m.ew); ENSURE(c->eku, uint32_t, ((size_t)E + 63) & ~(size_t)63, m.eku);
     ENSURE(c->ehist, int, E, m.ehist); ENSURE(c->ealive, unsigned char, E, m.ealive);
     ENSURE(c->ev_epoch, uint32_t, m.ev_cap, m.ev_epoch); ENSURE(c->ev_key, uint32_t, m.ev_cap, m.ev_key); ENSURE(c->ev_prev, int, m.ev_cap, m.ev_prev);
     ENSURE(c->racc, float, (size_t)(S0 + 1) * 12, m.racc); ENSURE(c->rrec, float, (size_t)(S0 + 1) * 16, m.rrec);
@@ -485,7 +494,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds) {
     rec_copy(c, m.ea, c->ea0.p, (size_t)E * 4);
     rec_copy(c, m.eb, c->eb0.p, (size_t)E * 4);
     MergeLds xl;
-    merge_fits_lds(E, S0, &xl);
+    merge_fits_lds(E, S0, &xl, keys_global);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u);
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
@@ -519,7 +528,8 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds) {
 }
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
-    if (c->merge_in_lds) rec<d_merge_lds>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds);
+    if (c->merge_in_lds && c->mlds.keys_in_lds) rec<d_merge_lds>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds);
+    else if (c->merge_in_lds) rec<d_merge_lds_big>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds);
     else rec<d_merge>(c, 1u, 0u, c->mdev);
     return F3DS_OK;
 }
@@ -561,8 +571,9 @@ void stage_mark(Batch& b, int i) { (void)hipEventRecord(b.owner->ev[i], b.st); }
 // cluster stage for the live frames (also the whole of f3ds_recluster)
 int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, const std::vector<int>& index_of, int labels_on_device, bool force_global = false) {
     bool all_lds = !force_global;
-    for (f3ds_ctx* c : b.fr) { MergeLds t; if (!merge_fits_lds(c->E, c->S0, &t)) all_lds = false; }
-    int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, all_lds); });
+    bool keys_global = false;        // one kernel for the whole batch: if any frame needs the 4-bytes-per-edge layout, all use it
+    for (f3ds_ctx* c : b.fr) { MergeLds t; if (!merge_fits_lds(c->E, c->S0, &t)) all_lds = false; else if (!t.keys_in_lds) keys_global = true; }
+    int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, all_lds, keys_global); });
     if (rc || (rc = flush(b))) return rc;
     stage_mark(b, 5);
     if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;

@@ -246,3 +246,25 @@ def test_dirty_tile_sweeps_are_bit_identical_at_any_setting(P, shift):
         assert got[n]["labels"] == gold[n]["labels_sha256"], (n, shift)
         for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
             assert got[n][w] == gold[n]["sha256"][w], (n, w, shift)
+
+
+@pytest.mark.gpu
+def test_merge_kernel_with_keys_in_global_memory(P):
+    """d_merge_lds_big (order keys outside LDS, used when a frame has too many adjacencies for 8 bytes per edge) gives
+    the same merges: forced here on golden cases through F3DS_FORCE_BIG_MERGE (read per call)."""
+    import hashlib, json, subprocess, sys
+    names = ["rgbd_320x240_ghosts", "rgbd_160x120_equalization", "fixture_launch_flags"]
+    code = (
+        "import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import conftest; from golden_cases import case_points, case_params\n"
+        "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
+        "for n in %r:\n"
+        "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
+        "    out[n] = dict(labels=hashlib.sha256(lab.tobytes()).hexdigest(), MERGES=hashlib.sha256(ctx.debug('MERGES').tobytes()).hexdigest())\n"
+        "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F3DS_FORCE_BIG_MERGE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+    for n in names:
+        assert got[n]["labels"] == gold[n]["labels_sha256"] and got[n]["MERGES"] == gold[n]["sha256"]["MERGES"], n
