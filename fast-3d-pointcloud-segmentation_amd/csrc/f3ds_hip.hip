@@ -119,7 +119,7 @@ struct f3ds_ctx {
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
     // device scratch (grow-only)
-    Buf pts, keys0, keys1, vals0, vals1, flags, incl, tiles, hist, seg_start, pt_voxel, labels;
+    Buf pts, spts, keys0, keys1, vals0, vals1, flags, incl, tiles, hist, seg_start, pt_voxel, labels;
     Buf vkey, vcount, vf, nbr, nbrT, hkeys, hvals, boxes, ckey, cell_start, chk, chv, chvals, seed_orig, keep, seed_kept;
     Buf owner0, owner1, ownR, dist0, dist1, R, hc, hcount, hlo, hhi, ghost_vox, ghost_active, ghost_done, ghost_head, ghost_next;
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
@@ -312,10 +312,11 @@ int seg_voxels(f3ds_ctx* c) {
     c->hmask = hcap - 1;
     ENSURE(c->vkey, uint32_t, (size_t)V * 3, vkey); ENSURE(c->vcount, uint32_t, V, vcount); ENSURE(c->vf, float, (size_t)V * 12, vf);
     ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hcap, hkeys); ENSURE(c->hvals, uint32_t, hcap, hvals);
-    rec_fill(c, c->pt_voxel.p, 0xFFFFFFFFu, (size_t)n * 4);
+    P16* spts; ENSURE(c->spts, P16, n, spts);
     rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hcap * 8);
-    rec<d_voxel_accum>(c, grid_for(V, 256), 0u, c->d_pts, (const uint64_t*)c->ks, (const uint32_t*)c->vs, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
-                       (const GridInfo*)c->d_grid, vkey, vcount, vf, (int*)c->pt_voxel.p, hkeys, hvals, c->hmask);
+    rec<d_point_gather>(c, grid_for(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
+    rec<d_voxel_accum>(c, grid_for(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
+                       (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask);
     rec<d_neighbors>(c, grid_for((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                      c->hmask, nbr, nbrT);
     rec<d_normals>(c, (V + NT_TILE - 1) / NT_TILE, 0u, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
