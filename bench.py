@@ -91,6 +91,8 @@ def main():
     # (wide stages on one stream per frame, all merge loops of the batch in ONE dispatch); `groups` such
     # calls run concurrently from host threads so one batch's wide stages overlap another's merge loops.
     nbatch, ngroups = max(1, args.batch), max(1, args.groups)
+    if args.steps < nbatch * ngroups:       # few steps: spread them over the groups instead of leaving groups idle
+        nbatch = max(1, -(-args.steps // ngroups))
     nstreams = nbatch * ngroups
     ctxs = [[P.Context(local_rank) for _ in range(nbatch)] for _ in range(ngroups)]
     # one contiguous label block per group: the batch's label output is ONE RCCL gather (nbatch x 4 MB per rank)
