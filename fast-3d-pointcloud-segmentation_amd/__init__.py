@@ -115,6 +115,9 @@ def load_library(path=None):
     lib.f3ds_auto_threshold.argtypes = [vp, ctypes.POINTER(Params), vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, sz, ctypes.POINTER(sz),
                                         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(Performance), vp, ctypes.c_int, ctypes.POINTER(Result)]
     lib.f3ds_auto_threshold.restype = ctypes.c_int
+    lib.f3ds_get_voxel_centroid_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_centroid_cloud.restype = ctypes.c_int
+    lib.f3ds_get_supervoxels.argtypes = [vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_supervoxels.restype = ctypes.c_int
+    lib.f3ds_get_supervoxel_adjacency.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_supervoxel_adjacency.restype = ctypes.c_int
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
     lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
     lib.f3ds_pcd_read.argtypes = [ctypes.c_char_p, vp, vp, sz, ctypes.POINTER(sz), u32p, u32p]; lib.f3ds_pcd_read.restype = ctypes.c_int
@@ -274,6 +277,33 @@ class Context:
         m = min(n.value, cap)
         return bt.value, bp, {float(ts[i]): ps[i].as_dict() for i in range(m)}, labels
 
+    def voxel_centroid_cloud(self):
+        """getVoxelCentroidCloud / getLabeledVoxelCloud: (xyz, rgba, supervoxel label) per voxel in leaf order."""
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_voxel_centroid_cloud(self.handle, None, None, None, 0, ctypes.byref(n)))
+        xyz = np.zeros((n.value, 3), np.float32); rgba = np.zeros(n.value, np.uint32); lab = np.zeros(n.value, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_voxel_centroid_cloud(self.handle, xyz.ctypes.data, rgba.ctypes.data, lab.ctypes.data, n.value, ctypes.byref(n)))
+        return xyz, rgba, lab
+
+    def supervoxels(self):
+        """The supervoxel_clusters map: dict of arrays label, xyz, rgb, normal, n_voxels (ascending label)."""
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_supervoxels(self.handle, None, None, None, None, None, 0, ctypes.byref(n)))
+        k = n.value
+        out = dict(label=np.zeros(k, np.uint32), xyz=np.zeros((k, 3), np.float32), rgb=np.zeros((k, 3), np.float32), normal=np.zeros((k, 3), np.float32),
+                   n_voxels=np.zeros(k, np.uint32))
+        _check(self.lib, self.lib.f3ds_get_supervoxels(self.handle, out["label"].ctypes.data, out["xyz"].ctypes.data, out["rgb"].ctypes.data, out["normal"].ctypes.data,
+                                                       out["n_voxels"].ctypes.data, k, ctypes.byref(n)))
+        return out
+
+    def supervoxel_adjacency(self):
+        """getSupervoxelAdjacency after clear_adjacency: (E, 2) array of label pairs a < b, sorted."""
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_supervoxel_adjacency(self.handle, None, 0, ctypes.byref(n)))
+        pairs = np.zeros((n.value, 2), np.uint32)
+        _check(self.lib, self.lib.f3ds_get_supervoxel_adjacency(self.handle, pairs.ctypes.data, n.value, ctypes.byref(n)))
+        return pairs
+
     def voxel_cloud(self):
         n = ctypes.c_size_t()
         _check(self.lib, self.lib.f3ds_get_voxel_cloud(self.handle, None, None, None, 0, ctypes.byref(n)))
@@ -351,6 +381,29 @@ class SupervoxelClustering:
 
     def setNormalImportance(self, v):
         self.params.w_normal = v
+
+    def extract(self):
+        """extract(supervoxel_clusters) (:356): runs the frame and returns the supervoxels (see Context.supervoxels)."""
+        if self.cloud is None:
+            raise LogicError(-5, "setInputCloud first")
+        self.ctx.segment(self.cloud, self.params)
+        self._extracted = True
+        return self.ctx.supervoxels()
+
+    def getVoxelCentroidCloud(self):               # :359 -> (xyz, rgba)
+        xyz, rgba, _ = self.ctx.voxel_centroid_cloud()
+        return xyz, rgba
+
+    def getLabeledVoxelCloud(self):                # voxel centroids with their supervoxel label
+        xyz, _, lab = self.ctx.voxel_centroid_cloud()
+        return xyz, lab
+
+    def makeSupervoxelNormalCloud(self):           # :360 -> (centroid xyz, normal) per supervoxel
+        sv = self.ctx.supervoxels()
+        return sv["xyz"], sv["normal"]
+
+    def getSupervoxelAdjacency(self):              # :365
+        return self.ctx.supervoxel_adjacency()
 
 
 class Clustering:

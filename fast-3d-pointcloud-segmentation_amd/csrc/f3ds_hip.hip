@@ -847,6 +847,69 @@ extern "C" int f3ds_get_voxel_cloud(f3ds_ctx* c, float* xyz, uint32_t* label, ui
     return (k > cap && (xyz || label || rgba)) ? F3DS_ERR_CAPACITY : F3DS_OK;
 }
 
+extern "C" int f3ds_get_voxel_centroid_cloud(f3ds_ctx* c, float* xyz, uint32_t* rgba, uint32_t* sv_label, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const uint32_t V = c->V;
+    if (n_out) *n_out = V;
+    if (!xyz && !rgba && !sv_label) return F3DS_OK;
+    if (cap < V) return F3DS_ERR_CAPACITY;
+    std::vector<float> f; std::vector<uint32_t> o;
+    int rc;
+    if ((rc = fetch(c, c->vf, (size_t)V * 12, f)) || (rc = fetch(c, c->owner0, V, o))) return rc;
+    for (uint32_t v = 0; v < V; ++v) {
+        const float* r = &f[(size_t)v * 12];
+        if (xyz) { xyz[3 * v] = r[0]; xyz[3 * v + 1] = r[1]; xyz[3 * v + 2] = r[2]; }
+        if (rgba) rgba[v] = ((uint32_t)r[3] & 255u) << 16 | ((uint32_t)r[4] & 255u) << 8 | ((uint32_t)r[5] & 255u);
+        if (sv_label) sv_label[v] = o[v];
+    }
+    return F3DS_OK;
+}
+
+extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const uint32_t S0 = c->S0;
+    std::vector<uint32_t> cnt; std::vector<float> hc;
+    int rc;
+    if ((rc = fetch(c, c->hcount, S0 + 1, cnt)) || (rc = fetch(c, c->hc, (size_t)(S0 + 1) * 12, hc))) return rc;
+    size_t k = 0;
+    for (uint32_t h = 1; h <= S0; ++h) {
+        if (!cnt[h]) continue;
+        if (k < cap) {
+            const float* r = &hc[(size_t)h * 12];
+            if (label) label[k] = h;
+            if (xyz) { xyz[3 * k] = r[0]; xyz[3 * k + 1] = r[1]; xyz[3 * k + 2] = r[2]; }
+            if (rgb) { rgb[3 * k] = r[3]; rgb[3 * k + 1] = r[4]; rgb[3 * k + 2] = r[5]; }
+            if (normal) { normal[3 * k] = r[6]; normal[3 * k + 1] = r[7]; normal[3 * k + 2] = r[8]; }
+            if (n_voxels) n_voxels[k] = cnt[h];
+        }
+        k++;
+    }
+    if (n_out) *n_out = k;
+    return (k > cap && (label || xyz || rgb || normal || n_voxels)) ? F3DS_ERR_CAPACITY : F3DS_OK;
+}
+
+extern "C" int f3ds_get_supervoxel_adjacency(f3ds_ctx* c, uint32_t* pairs, size_t cap_pairs, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const uint32_t E = c->E;
+    if (n_out) *n_out = E;
+    if (!pairs) return F3DS_OK;
+    if (cap_pairs < E) return F3DS_ERR_CAPACITY;
+    std::vector<uint32_t> a, b;
+    int rc;
+    if ((rc = fetch(c, c->ea0, E, a)) || (rc = fetch(c, c->eb0, E, b))) return rc;
+    for (uint32_t e = 0; e < E; ++e) { pairs[2 * e] = a[e]; pairs[2 * e + 1] = b[e]; }
+    return F3DS_OK;
+}
+
 extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes, size_t* bytes_out) {
     if (!c) return F3DS_ERR_ARG;
     HIPCHECK(hipSetDevice(c->device));

@@ -164,6 +164,21 @@ enum {
 };
 int f3ds_get_debug(f3ds_ctx* ctx, int what, void* dst, size_t cap_bytes, size_t* bytes_out);
 
+/* ---- the VCCS result itself: what main() reads back from pcl::SupervoxelClustering after extract()
+ * (src/supervoxel_clustering.cpp:359-367).  All valid after f3ds_segment; call with NULL outputs for the count. */
+
+/* getVoxelCentroidCloud (:359) + getLabeledVoxelCloud: one entry per voxel in leaf order: centroid, mean colour
+ * as 0x00RRGGBB (VoxelData::getPoint truncation), supervoxel label (0 = none). */
+int f3ds_get_voxel_centroid_cloud(f3ds_ctx* ctx, float* xyz, uint32_t* rgba, uint32_t* sv_label, size_t cap, size_t* n_out);
+
+/* the supervoxel_clusters map + makeSupervoxelNormalCloud (:356,360): per non-empty supervoxel, ascending label:
+ * label, centroid xyz, mean rgb (float), unit normal, number of voxels. */
+int f3ds_get_supervoxels(f3ds_ctx* ctx, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels,
+                         size_t cap, size_t* n_out);
+
+/* getSupervoxelAdjacency (:365) after clear_adjacency: pairs (a < b) of adjacent supervoxel labels, sorted. */
+int f3ds_get_supervoxel_adjacency(f3ds_ctx* ctx, uint32_t* pairs, size_t cap_pairs, size_t* n_out);
+
 /* ---- evaluation against ground truth and automatic threshold (the path run when -t is omitted) ----
  * Mirrors Testing::eval_performance (src/testing.cpp:239-406) and Clustering::all_thresh / best_thresh
  * (src/clustering.cpp:691-774) on the frame of the last f3ds_segment call.  truth_point_labels holds

@@ -268,3 +268,26 @@ def test_merge_kernel_with_keys_in_global_memory(P):
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
     for n in names:
         assert got[n]["labels"] == gold[n]["labels_sha256"] and got[n]["MERGES"] == gold[n]["sha256"]["MERGES"], n
+
+
+@pytest.mark.gpu
+def test_vccs_getters_match_oracle(P, oracle, gpu_ctx):
+    """getVoxelCentroidCloud / supervoxel_clusters / makeSupervoxelNormalCloud / getSupervoxelAdjacency
+    (src/supervoxel_clustering.cpp:356-365) through the public accessors and the SupervoxelClustering mirror."""
+    pts = case_points(P, "rgbd_320x240_ghosts"); prm = case_params(P, "rgbd_320x240_ghosts")
+    sv = P.SupervoxelClustering(prm.voxel_res, prm.seed_res, context=gpu_ctx); sv.setInputCloud(pts)
+    clusters = sv.extract()
+    rc, _, ores, h = oracle.segment(pts, prm)
+    assert rc == 0
+    xyz, rgba = sv.getVoxelCentroidCloud(); lxyz, lab = sv.getLabeledVoxelCloud()
+    assert np.array_equal(xyz.view(np.uint32), h.get("VOXEL_XYZ").reshape(-1, 3).view(np.uint32)) and np.array_equal(lab, h.get("VOXEL_SVLABEL"))
+    rgb = h.get("VOXEL_RGB").reshape(-1, 3).astype(np.uint32)
+    assert np.array_equal(rgba, (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2])
+    cen = h.get("SV_CENTROID").reshape(-1, 10)
+    assert np.array_equal(clusters["label"], h.get("SV_LABELS")) and len(clusters["label"]) == ores.n_supervoxels
+    assert np.array_equal(clusters["xyz"].view(np.uint32), cen[:, 0:3].copy().view(np.uint32))
+    assert np.array_equal(clusters["rgb"].view(np.uint32), cen[:, 3:6].copy().view(np.uint32))
+    nxyz, nrm = sv.makeSupervoxelNormalCloud()
+    assert np.array_equal(nrm.view(np.uint32), cen[:, 6:9].copy().view(np.uint32))
+    assert clusters["n_voxels"].sum() >= int((lab != 0).sum())             # every owned voxel is a leaf (a ghost leaf counts twice)
+    assert np.array_equal(sv.getSupervoxelAdjacency(), h.get("EDGES").reshape(-1, 2))
