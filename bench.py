@@ -45,7 +45,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 STAGES = ["voxelise", "neighbours+normals", "seeds", "sweeps", "summaries+adjacency+weights", "merge", "labels"]
 # the kernel that dominates each stage (rocprofv3 --kernel-trace names in profiles/)
 STAGE_KERNEL = {"voxelise": "k_batched<d_radix_scatter>", "neighbours+normals": "k_batched<d_normals>", "seeds": "k_batched<d_seed_nn>", "sweeps": "k_batched<d_sweep_R>",
-                "summaries+adjacency+weights": "k_batched<d_sv_fill>", "merge": "k_batched<d_merge_lds>", "labels": "k_batched<d_point_labels>"}
+                "summaries+adjacency+weights": "k_batched<d_sv_fill>", "merge": "k_batched<d_merge_lds_t<true>>", "labels": "k_batched<d_point_labels>"}
 ALG_BYTES_PER_POINT = 20          # 16 B read of {x,y,z,rgba} + 4 B label write
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 
@@ -181,7 +181,7 @@ def main():
         traffic = None
         try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))
-            kname = STAGE_KERNEL[STAGES[dom]].split("<")[1].rstrip(">")
+            kname = STAGE_KERNEL[STAGES[dom]].split("<")[1].rstrip(">")      # d_merge_lds_t, d_sweep_R, ...
             if kname in pm["kernels"]:
                 traffic = int(pm["kernels"][kname]["hbm_bytes_per_frame"] * frames_per_launch)
         except Exception:
