@@ -1,18 +1,21 @@
 // f3ds_hip.hip -- the MI355X (gfx950) device pipeline behind include/f3ds.h.
 //
-// Stage map (reference citations are in include/f3ds.h, csrc/f3ds_numerics.h, csrc/f3ds_algo.h):
-//   0 voxelise   k_bbox -> k_grid -> k_keys -> radix sort -> k_heads/scan/k_segstart -> k_voxel_accum
-//   1 neighbours k_neighbors (hash probe of the 27 cells), k_normals (two-ring ordered covariance)
-//   2 seeds      k_chunkbox, k_seed_grow, k_seed_keys, radix sort, k_cell_hash, k_seed_nn, k_seed_filter
-//   3 sweeps     per sweep: k_ghost_relink, k_sweep_R, k_sweep_claim, k_centroid
-//   4 summaries  k_sv_fill (payload rows + ordered leaf sums), k_edges, radix sort, k_edge_init,
-//                k_edge_deltas, k_lambda / k_cdf, k_edge_weights
-//   5 merge      k_merge (one persistent workgroup), k_roots
-//   6 labels     k_region_rank (+scan), k_point_labels
+// Stage map (kernel functors d_<name> live in f3ds_kernels.inc; reference citations are in include/f3ds.h,
+// csrc/f3ds_numerics.h, csrc/f3ds_algo.h):
+//   0 voxelise   d_bbox -> d_grid -> d_keys -> radix sort -> d_heads/scan/d_segstart -> d_point_gather -> d_voxel_accum
+//   1 neighbours d_neighbors (hash probe of the 27 cells), d_normals (two-ring ordered covariance, LDS tile)
+//   2 seeds      d_chunkbox, d_seed_grow, d_seed_keys, radix sort, d_cell_hash, d_seed_nn, d_seed_filter
+//   3 sweeps     per sweep: d_sweep_begin, d_sweep_R_round x4 | d_sweep_R_pre + d_sweep_R, d_sweep_claim, d_claim_mark,
+//                d_centroid, d_centroid_mark  
+//   4 summaries  d_sv_fill (payload rows + ordered leaf sums), d_edges, radix sort, d_edge_init,
+//                d_edge_deltas, d_lambda / d_cdf_*, d_edge_weights
+//   5 merge      d_merge_lds / d_merge_lds_big (one persistent workgroup per frame, LDS resident), d_merge (global memory)
+//   6 labels     d_roots (+scan), d_point_labels
+// Every frame RECORDS its kernel calls; flush() zips the records of a batch into one dispatch per kernel (grid.y = frame).
 //
 // Layout in HBM: points stay as the caller's 16-byte records (one global_load_dwordx4 per lane);
 // everything per voxel is SoA rows of 12 floats (48 B, 16-B aligned: xyz rgb normal pad) so a
-// lane reads a neighbour with three dwordx4 loads; per-voxel neighbour table is V x 27 int32.
+// lane reads a neighbour with three dwordx4 loads; per-voxel neighbour table is V x 27 int32 (plus its 27 x V transpose).
 // Float summation order is the reference's everywhere: parallel across outputs, sequential in
 // reference order inside each reduction.  Built with -ffp-contract=off.
 #include <hip/hip_runtime.h>

@@ -41,7 +41,7 @@ def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name):
 
 
 def test_global_memory_merge_kernel_matches_too(P, oracle, monkeypatch):
-    """k_merge (edges in HBM, used when they do not fit LDS) against the oracle."""
+    """d_merge (edges in HBM, used when they do not fit LDS) against the oracle."""
     monkeypatch.setenv("F3DS_FORCE_GLOBAL_MERGE", "1")
     ctx = P.Context(0)
     for name in ("rgbd_320x240_ghosts", "fixture_launch_flags"):
