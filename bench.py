@@ -79,6 +79,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     P = importlib.import_module("fast-3d-pointcloud-segmentation_amd")
+    B = importlib.import_module("fast-3d-pointcloud-segmentation_amd.batch")
     prm = P.launch_params(voxel_res=0.008, seed_res=0.08)          # -v 0.008 -s 0.08 --AL --CVX -t 0.2
     if os.environ.get("F3DS_BENCH_THRESHOLD"):                    # development only: what-if runs (the JSON line then names the threshold)
         prm.threshold = float(os.environ["F3DS_BENCH_THRESHOLD"])
@@ -124,7 +125,7 @@ def main():
                                     labels_out=[label_bufs[g][i].data_ptr() for i in range(k)], n=[npts] * k, on_device=True)
                     if world > 1:   # label output of this batch: one RCCL gather of the whole label block to rank 0
                         with stage_lock:
-                            dist.gather(label_blocks[g], gather_list, dst=0)
+                            B.gather_label_block(label_blocks[g], dist, gather_list, dst=0)
                     if record:      # ms_stage is the device time of each stage of the whole batch (HIP events on the batch stream)
                         with stage_lock:
                             for j in range(7):

@@ -30,3 +30,16 @@ def gather_labels(local_labels, dist, dst=0):
                 if k < int(slots[r].item()):
                     out[r + k * world] = bufs[r]
     return out
+
+
+def gather_label_block(block, dist, bufs=None, dst=0):
+    """The form bench.py uses: the label output of a whole batch (a contiguous [frames, points] int32 block per rank)
+    goes to rank `dst` in ONE collective.  `bufs` (rank dst only): preallocated list of world blocks, reused
+    across batches.  Returns the list on dst, None elsewhere.  Collectives on one communicator must not be issued
+    concurrently from several threads: callers with several batches in flight serialise this call."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if rank == dst and bufs is None:
+        bufs = [torch.empty_like(block) for _ in range(world)]
+    dist.gather(block, bufs if rank == dst else None, dst=dst)
+    return bufs if rank == dst else None

@@ -50,6 +50,50 @@ def test_two_rank_shard_and_gather(n_frames):
     assert q.get(timeout=10) is True
 
 
+def _block_worker(rank, world, port, nbatch, npts, q):
+    """bench.py's pattern: several batches in flight per rank (threads), each ends with one gather of its label block."""
+    import threading
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    B = importlib.import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    lock = threading.Lock()
+    bufs = [torch.empty((nbatch, npts), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    seen = []
+
+    def group(g):
+        for it in range(3):
+            block = torch.full((nbatch, npts), rank * 100 + 1, dtype=torch.int32)        # every batch of a rank looks the same
+            with lock:
+                got = B.gather_label_block(block, dist, bufs, dst=0)
+                if rank == 0:
+                    seen.append([int(b[0, 0]) for b in got])
+
+    ts = [threading.Thread(target=group, args=(g,)) for g in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if rank == 0:
+        q.put(len(seen) == 9 and all(s == [r * 100 + 1 for r in range(world)] for s in seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_block_gather_from_threads():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_block_worker, args=(r, 2, port, 4, 3000, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
 def test_round_robin_partition():
     B = __import__("importlib").import_module("fast-3d-pointcloud-segmentation_amd.batch")
     for world in (1, 2, 4, 8):
