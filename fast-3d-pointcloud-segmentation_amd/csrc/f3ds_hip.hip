@@ -187,6 +187,8 @@ struct Batch {
     f3ds_ctx* owner = nullptr;     // holds the argument arena and the stage events
 };
 
+thread_local double g_t_wait = 0, g_t_launch = 0;
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // zip the recorded calls of all live frames into batched dispatches
 int flush(Batch& b) {
     if (b.fr.empty()) return F3DS_OK;
@@ -207,7 +209,8 @@ int flush(Batch& b) {
         HIPCHECK(hipMalloc((void**)&o->d_args, o->args_cap));
     }
     // the pinned arena may still feed an earlier, not yet completed copy
-    HIPCHECK(hipStreamSynchronize(b.st));
+    { const double t0 = now_ms(); HIPCHECK(hipStreamSynchronize(b.st)); g_t_wait += now_ms() - t0; }
+    const double tl0 = now_ms();
     for (size_t j = 0; j < ncmd; ++j)
         for (uint32_t i = 0; i < nf; ++i) {
             const Cmd& cm = b.fr[i]->cmds[j];
@@ -221,6 +224,7 @@ int flush(Batch& b) {
         HIPCHECK(b.fr[0]->cmds[j].fn(gx, nf, lds, b.st, o->d_args + off[j]));
     }
     for (f3ds_ctx* c : b.fr) { c->cmds.clear(); c->blob.clear(); }
+    g_t_launch += now_ms() - tl0;
     return F3DS_OK;
 }
 // flush, then bring every live frame's counters to the host
@@ -244,7 +248,7 @@ int flush_sync(Batch& b) {
         if ((rc = flush(b))) return rc;
         HIPCHECK(hipMemcpyAsync(o->h_dcblk, o->d_dcblk, nf * sizeof(DevCounters), hipMemcpyDeviceToHost, b.st));
     }
-    HIPCHECK(hipStreamSynchronize(b.st));
+    { const double t0 = now_ms(); HIPCHECK(hipStreamSynchronize(b.st)); g_t_wait += now_ms() - t0; }
     HIPCHECK(hipGetLastError());
     if (nf > 1) for (size_t i = 0; i < nf; ++i) *b.fr[i]->h_dc = b.owner->h_dcblk[i];
     return F3DS_OK;
@@ -691,6 +695,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if (!(prm->voxel_res > 0) || !(prm->seed_res > 0)) return F3DS_ERR_ARG;
     for (int i = 0; i < nctx; ++i) if (!ctxs[i] || (!points[i] && counts[i]) || counts[i] > 0x7fffffffull || ctxs[i]->device != ctxs[0]->device) return F3DS_ERR_ARG;
     const auto t0 = std::chrono::steady_clock::now();
+    g_t_wait = 0; g_t_launch = 0;
     HIPCHECK(hipSetDevice(ctxs[0]->device));
     Batch b;
     b.owner = ctxs[0]; b.st = ctxs[0]->stream;
@@ -772,6 +777,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     // device time of each stage of the whole batch (HIP events on the batch's stream)
     for (int k = 0; k < 7; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[k], b.owner->ev[k + 1]) == hipSuccess) stage[k] = ms; }
     const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("F3DS_HOST_PROF")) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch);
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
         for (int k = 0; k < 8; ++k) c->res.ms_stage[k] = stage[k];
