@@ -127,7 +127,7 @@ struct f3ds_ctx {
     Buf owner0, owner1, ownR, dist0, dist1, R, hc, hcount, hlo, hhi, ghost_vox, ghost_active, ghost_done, ghost_head, ghost_next;
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
-    Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
+    Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
@@ -381,7 +381,7 @@ int seg_sweeps(f3ds_ctx* c) {
     uint32_t *tiles4, *trr, *hD;
     ENSURE(c->tstamp, uint32_t, (size_t)4 * T, tiles4); ENSURE(c->tround, uint32_t, (size_t)(F3DS_R_ROUNDS - 1) * T, trr); ENSURE(c->hdirty, uint32_t, S0 + 1, hD);
     uint32_t *tl, *tcnt; ENSURE(c->htiles, uint32_t, (size_t)(S0 + 1) * HT_CAP, tl); ENSURE(c->htcnt, uint32_t, S0 + 1, tcnt);
-    uint32_t *chg, *wl; ENSURE(c->vchg, uint32_t, V, chg); ENSURE(c->vwl, uint32_t, V, wl);
+    uint32_t *chg, *wl, *wl2; ENSURE(c->vchg, uint32_t, V, chg); ENSURE(c->vwl, uint32_t, V, wl); ENSURE(c->vwl2, uint32_t, V, wl2);
     rec_fill(c, chg, 0u, (size_t)V * 4);
     rec_fill(c, tiles4, 0u, (size_t)4 * T * 4);
     rec_fill(c, trr, 0u, (size_t)(F3DS_R_ROUNDS - 1) * T * 4);
@@ -398,14 +398,14 @@ int seg_sweeps(f3ds_ctx* c) {
     a.R = R; a.ownR = ownR; a.owner_out = owner0; a.dist_out = dist0;
     a.ghost_done = ghost_done; a.ghost_active = ghost_active; a.ghost_vox = ghost_vox; a.ghost_head = ghost_head; a.ghost_next = ghost_next;
     a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
-    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.chg = chg; a.wl = wl;
+    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.chg = chg; a.wl = wl; a.wl2 = wl2;
     a.thr = g_inc_shift >= 32 ? 0xFFFFFFFFu : (g_inc_shift < 0 ? 0u : V >> g_inc_shift);
     for (uint32_t t = 0; t < c->res.sweeps; ++t) {
         if (a_sweep_needs_clear(t)) rec_fill(c, R, 0u, V);
         rec<d_sweep_begin>(c, 1u, 0u, a, t);
         if (g_inc_shift >= 0) for (uint32_t r = 0; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
         rec<d_sweep_R_pre>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t);
-        rec<d_sweep_R>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t);
+        for (uint32_t pass = 0; pass < F3DS_R_PASSES; ++pass) rec<d_sweep_R>(c, pass == 0 ? grid_for(V, 256) : 64u, 0u, a, a_sweep_tag(t), t, pass);
         rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
         if (g_inc_shift >= 0) rec<d_claim_mark>(c, grid_for(V, 256), 0u, a, t);
         rec<d_centroid>(c, (S0 + 3u) / 4u + (S0 ? 0u : 1u), 0u, a, t);

@@ -309,8 +309,19 @@ int stage_sweeps(f3ds_emul& E) {
             int overflow = 0;
             const unsigned char tag = a_sweep_tag(t);
             std::fill(R.begin(), R.end(), (unsigned char)0);
-            for (int v = 0; v < V; ++v) { bool r = E.owner[v] ? a_eval_R(s, v, R.data(), tag, &overflow) : false; ownR[v] = E.owner[v] | (r ? F3DS_OWNR_RTRUE : 0u); }
-            if (overflow) return F3DS_ERR_UNSUPPORTED;
+            // like d_sweep_R: voxels whose chain is deeper than the walker's stack are retried in later passes over the memo
+            std::vector<int> todo, again;
+            for (int v = 0; v < V; ++v) { if (E.owner[v]) todo.push_back(v); else ownR[v] = 0u; }
+            for (int pass = 0; pass < F3DS_R_PASSES && !todo.empty(); ++pass) {
+                again.clear();
+                for (int v : todo) {
+                    overflow = 0;
+                    const bool r = a_eval_R(s, v, R.data(), tag, &overflow);
+                    if (overflow) again.push_back(v); else ownR[v] = E.owner[v] | (r ? F3DS_OWNR_RTRUE : 0u);
+                }
+                todo.swap(again);
+            }
+            if (!todo.empty()) return F3DS_ERR_UNSUPPORTED;
         }
         // claim, in place
         std::fill(done.begin(), done.end(), 0);

@@ -291,3 +291,34 @@ def test_vccs_getters_match_oracle(P, oracle, gpu_ctx):
     assert np.array_equal(nrm.view(np.uint32), cen[:, 6:9].copy().view(np.uint32))
     assert clusters["n_voxels"].sum() >= int((lab != 0).sum())             # every owned voxel is a leaf (a ghost leaf counts twice)
     assert np.array_equal(sv.getSupervoxelAdjacency(), h.get("EDGES").reshape(-1, 2))
+
+
+@pytest.mark.gpu
+def test_random_small_frames_and_parameters(P, oracle, gpu_ctx):
+    """Seeded sweep over frame sizes, NaN rates, resolutions, metrics, merging modes, thresholds, leaf orders and
+    importances: every intermediate array of the device path equals the oracle's, byte for byte."""
+    rng = np.random.default_rng(20260930)
+    ran = 0
+    for it in range(24):
+        w, hgt = int(rng.integers(40, 200)), int(rng.integers(30, 160))
+        kind = int(rng.integers(0, 2))
+        pts = P.synth_frame(kind, int(rng.integers(1, 10**6)), w, hgt, int(rng.integers(0, 300)) if kind == 0 else 0)
+        vres = float(rng.choice([0.01, 0.015, 0.02, 0.03, 0.05]))
+        prm = P.launch_params(voxel_res=vres, seed_res=vres * float(rng.choice([3, 5, 8, 12])),
+                              use_transform=int(rng.integers(0, 2)) if kind == 0 else 0, color_metric=int(rng.integers(0, 2)),
+                              geom_metric=int(rng.integers(0, 2)), merging=int(rng.integers(0, 3)), lambda_=float(rng.uniform(0.05, 0.95)),
+                              bins=int(rng.choice([0, 20, 100])), threshold=float(rng.choice([0.0, 0.1, 0.3, 0.6, 1.0])),
+                              leaf_order=int(rng.integers(0, 2)), w_color=float(rng.uniform(0.1, 1.0)), w_spatial=float(rng.uniform(0.1, 1.0)),
+                              w_normal=float(rng.uniform(0.5, 6.0)))
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        if rc != 0:                      # the same refusal on both sides (e.g. the equalization bin overrun)
+            with pytest.raises(Exception):
+                gpu_ctx.segment(pts, prm)
+            continue
+        lab = gpu_ctx.segment(pts, prm)
+        assert np.array_equal(lab, olab), (it, first_mismatch(lab, olab))
+        for wname in ALL_DEBUG:
+            a, b = gpu_ctx.debug(wname), oh.get(wname)
+            assert a.tobytes() == b.tobytes(), (it, wname)
+        ran += 1
+    assert ran >= 16
