@@ -958,10 +958,14 @@ int f3ds_oracle_cluster(f3ds_oracle* op, const f3ds_params* prm, uint32_t* label
     uint32_t cur = 0;
     o.voxel_region.assign(o.vox.size(), F3DS_NO_LABEL);
     for (auto& kv : o.segments) {
-        for (int vi : kv.second->voxel_idx) o.voxel_region[vi] = cur;
         for (uint32_t leaf : kv.second->leaves) root_of_leaf[leaf] = kv.first;
         rank_of_label[kv.first] = cur++;
     }
+    // A voxel takes the region of the supervoxel that OWNS it (pcl getLabeledCloud reads leaf.owner_).  A
+    // "ghost" leaf (two seeds on one voxel) also sits in another supervoxel's voxel list when the sweeps end before it
+    // is resolved (very small seed / voxel ratios); that membership shows in get_labeled_cloud, not in the point labels.
+    for (size_t vi = 0; vi < o.vox.size(); ++vi)
+        if (o.vox[vi].svlabel) o.voxel_region[vi] = rank_of_label[root_of_leaf[o.vox[vi].svlabel]];
     o.sv_region.clear();
     for (uint32_t l : o.sv_labels) o.sv_region.push_back(root_of_leaf[l]);
     if (labels)
