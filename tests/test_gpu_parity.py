@@ -297,9 +297,9 @@ def test_vccs_getters_match_oracle(P, oracle, gpu_ctx):
 def test_random_small_frames_and_parameters(P, oracle, gpu_ctx):
     """Seeded sweep over frame sizes, NaN rates, resolutions, metrics, merging modes, thresholds, leaf orders and
     importances: every intermediate array of the device path equals the oracle's, byte for byte."""
-    rng = np.random.default_rng(20260930)
+    rng = np.random.default_rng(int(os.environ.get("F3DS_FUZZ_SEED", "20260930")))
     ran = 0
-    for it in range(24):
+    for it in range(int(os.environ.get("F3DS_FUZZ_CASES", "24"))):
         w, hgt = int(rng.integers(40, 200)), int(rng.integers(30, 160))
         kind = int(rng.integers(0, 2))
         pts = P.synth_frame(kind, int(rng.integers(1, 10**6)), w, hgt, int(rng.integers(0, 300)) if kind == 0 else 0)
