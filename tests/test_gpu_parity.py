@@ -300,16 +300,16 @@ def test_random_small_frames_and_parameters(P, oracle, gpu_ctx):
     rng = np.random.default_rng(int(os.environ.get("F3DS_FUZZ_SEED", "20260930")))
     ran = 0
     for it in range(int(os.environ.get("F3DS_FUZZ_CASES", "24"))):
-        w, hgt = int(rng.integers(40, 200)), int(rng.integers(30, 160))
+        w, hgt = int(rng.integers(20, 260)), int(rng.integers(20, 200))
         kind = int(rng.integers(0, 2))
-        pts = P.synth_frame(kind, int(rng.integers(1, 10**6)), w, hgt, int(rng.integers(0, 300)) if kind == 0 else 0)
-        vres = float(rng.choice([0.01, 0.015, 0.02, 0.03, 0.05]))
-        prm = P.launch_params(voxel_res=vres, seed_res=vres * float(rng.choice([3, 5, 8, 12])),
+        pts = P.synth_frame(kind, int(rng.integers(1, 10**6)), w, hgt, int(rng.integers(0, 400)) if kind == 0 else 0)
+        vres = float(rng.choice([0.008, 0.01, 0.015, 0.02, 0.03, 0.05, 0.08]))
+        prm = P.launch_params(voxel_res=vres, seed_res=vres * float(rng.choice([2, 3, 5, 8, 12, 20])),
                               use_transform=int(rng.integers(0, 2)) if kind == 0 else 0, color_metric=int(rng.integers(0, 2)),
-                              geom_metric=int(rng.integers(0, 2)), merging=int(rng.integers(0, 3)), lambda_=float(rng.uniform(0.05, 0.95)),
-                              bins=int(rng.choice([0, 20, 100])), threshold=float(rng.choice([0.0, 0.1, 0.3, 0.6, 1.0])),
-                              leaf_order=int(rng.integers(0, 2)), w_color=float(rng.uniform(0.1, 1.0)), w_spatial=float(rng.uniform(0.1, 1.0)),
-                              w_normal=float(rng.uniform(0.5, 6.0)))
+                              geom_metric=int(rng.integers(0, 2)), merging=int(rng.integers(0, 3)), lambda_=float(rng.uniform(0.0, 1.0)),
+                              bins=int(rng.choice([0, 5, 20, 100, 500])), threshold=float(rng.choice([0.0, 0.05, 0.1, 0.3, 0.6, 1.0])),
+                              leaf_order=int(rng.integers(0, 2)), w_color=float(rng.uniform(0.0, 1.0)), w_spatial=float(rng.uniform(0.0, 1.0)),
+                              w_normal=float(rng.uniform(0.0, 6.0)))
         rc, olab, ores, oh = oracle.segment(pts, prm)
         if rc != 0:                      # the same refusal on both sides (e.g. the equalization bin overrun)
             with pytest.raises(Exception):
