@@ -322,3 +322,56 @@ def test_random_small_frames_and_parameters(P, oracle, gpu_ctx):
             assert a.tobytes() == b.tobytes(), (it, wname)
         ran += 1
     assert ran >= 16
+
+
+@pytest.mark.gpu
+def test_random_recluster_evaluation_and_batches(P, oracle):
+    """Seeded sweep over the other entry points: f3ds_recluster with changed metrics, f3ds_evaluate and
+    f3ds_auto_threshold with random ground truth, and f3ds_segment_batch over ragged mixes of frames."""
+    rng = np.random.default_rng(int(os.environ.get("F3DS_FUZZ_SEED", "777")))
+    ncase = int(os.environ.get("F3DS_FUZZ_CASES", "8"))
+    ctx = P.Context(0)
+    for it in range(ncase):
+        w, hgt = int(rng.integers(60, 220)), int(rng.integers(50, 160))
+        pts = P.synth_frame(0, int(rng.integers(1, 10**6)), w, hgt, int(rng.integers(0, 200)))
+        vres = float(rng.choice([0.012, 0.02, 0.03]))
+        prm = P.launch_params(voxel_res=vres, seed_res=vres * float(rng.choice([4, 8, 12])), threshold=float(rng.choice([0.1, 0.3])))
+        ctx.segment(pts, prm)
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        assert rc == 0
+        # recluster with other metrics / threshold
+        p2 = P.launch_params(voxel_res=prm.voxel_res, seed_res=prm.seed_res, color_metric=int(rng.integers(0, 2)), geom_metric=int(rng.integers(0, 2)),
+                             merging=int(rng.integers(0, 2)), lambda_=float(rng.uniform(0.1, 0.9)), threshold=float(rng.choice([0.05, 0.2, 0.5, 1.0])))
+        l2 = ctx.recluster(p2)
+        rc, ol2, _ = oh.cluster(p2, len(pts))
+        assert rc == 0 and np.array_equal(l2, ol2), it
+        # evaluation against random ground truth (blocks of the image plus noise)
+        truth = ((np.arange(len(pts)) // w // 16) * 7 + (np.arange(len(pts)) % w) // 16).astype(np.uint32) % int(rng.integers(3, 400))
+        truth[rng.random(len(pts)) < 0.01] = int(rng.integers(0, 1000))
+        rc, want = oh.evaluate(truth)
+        assert rc == 0 and ctx.evaluate(truth).as_dict() == want.as_dict(), it
+        sweep = (float(rng.choice([0.0, 0.1])), float(rng.choice([0.5, 1.0])), float(rng.choice([0.05, 0.125])))
+        bt, bp, table, labels = ctx.auto_threshold(p2, truth, *sweep)
+        rc, obt, obp, otable, olabels = oh.auto_threshold(p2, truth, len(pts), *sweep)
+        assert rc == 0 and bt == obt and table == otable and np.array_equal(labels, olabels), it
+    ctx.close()
+    # batches: ragged sizes, an empty frame, an all-NaN frame, duplicates
+    for it in range(max(2, ncase // 4)):
+        frames = []
+        for k in range(int(rng.integers(2, 7))):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                frames.append(np.zeros((0, 4), np.float32))
+            elif kind == 1:
+                f = P.synth_frame(0, int(rng.integers(1, 10**6)), 40, 30, 0); f[:, :3] = np.nan; frames.append(f)
+            else:
+                frames.append(P.synth_frame(int(rng.integers(0, 2)), int(rng.integers(1, 10**6)), int(rng.integers(30, 200)), int(rng.integers(30, 150)), 50 * (kind == 2)))
+        prm = P.launch_params(voxel_res=0.02, seed_res=float(rng.choice([0.1, 0.2])), use_transform=0)
+        ctxs = [P.Context(0) for _ in frames]
+        got = P.segment_batch(ctxs, frames, prm)
+        for f, g, c in zip(frames, got, ctxs):
+            rc, olab, ores, _ = oracle.segment(f, prm)
+            assert rc == 0 and np.array_equal(olab, g), it
+            assert c.result.n_regions == ores.n_regions and c.result.n_voxels == ores.n_voxels
+        for c in ctxs:
+            c.close()
