@@ -119,6 +119,7 @@ struct f3ds_ctx {
     uint64_t *eks = nullptr;                             // sorted edge keys
     f3ds_result res;
     bool merge_in_lds = false;
+    uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
     // device scratch (grow-only)
@@ -188,6 +189,13 @@ struct Batch {
 };
 
 thread_local double g_t_wait = 0, g_t_launch = 0;
+// F3DS_TRACE_ERR=1: say which stage refused a frame (development aid)
+static int trace_err(int code, const char* where, const f3ds_ctx* c) {
+    if (code && getenv("F3DS_TRACE_ERR"))
+        fprintf(stderr, "f3ds: error %d after %s (V %u, seeds %u, edges %u, chain overflow %d, rq %u %u %u %u %u %u)\n", code, where, c->V, c->S0, c->h_dc->n_edges,
+                c->h_dc->r_overflow, c->h_dc->rq[0], c->h_dc->rq[1], c->h_dc->rq[2], c->h_dc->rq[3], c->h_dc->rq[4], c->h_dc->rq[5]);
+    return code;
+}
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // zip the recorded calls of all live frames into batched dispatches
 int flush(Batch& b) {
@@ -483,7 +491,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds, bool ke
     MergeDev m;
     memset(&m, 0, sizeof m);
     m.E = E; m.S0 = S0; m.threshold = prm->threshold; m.dc = c->d_dc;
-    m.ev_cap = E * 64u + 4096u;
+    { const uint64_t cap = (uint64_t)E * c->ev_mult + 4096u; m.ev_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }      // weight-history events: grown on demand (run_cluster)
     ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, E, m.ew); ENSURE(c->eku, uint32_t, ((size_t)E + 63) & ~(size_t)63, m.eku);
     ENSURE(c->ehist, int, E, m.ehist); ENSURE(c->ealive, unsigned char, E, m.ealive);
     ENSURE(c->ev_epoch, uint32_t, m.ev_cap, m.ev_epoch); ENSURE(c->ev_key, uint32_t, m.ev_cap, m.ev_key); ENSURE(c->ev_prev, int, m.ev_cap, m.ev_prev);
@@ -596,6 +604,19 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         c->user_labels = nullptr;
     }
     if ((rc = flush_sync(b))) return rc;
+    {
+        // a frame whose merge loop re-weights more edges than its event arrays hold (huge regions of tiny supervoxels)
+        // runs the stage again -- it starts from the untouched supervoxel state -- with four times the room
+        bool again = false;
+        for (f3ds_ctx* c : b.fr) if (c->h_dc->ev_overflow && c->ev_mult < 16384u) { c->ev_mult *= 4u; again = true; }
+        if (again) {
+            for (f3ds_ctx* c : b.fr) {
+                c->h_dc->error = 0; c->h_dc->ev_overflow = 0;
+                HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->ev_overflow, 0, sizeof(int), b.st));
+            }
+            return run_cluster(b, prm, labels_of, index_of, labels_on_device, force_global);
+        }
+    }
     if (all_lds) {
         // a merge whose two regions touch more than ML_TL_CAP edges does not fit the LDS kernel's lists: the stage
         // (it starts from the untouched supervoxel state) runs again with the global-memory kernel
@@ -607,7 +628,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         }
     }
     for (f3ds_ctx* c : b.fr) {
-        if (c->h_dc->error) return c->h_dc->error;
+        if (c->h_dc->error) return trace_err(c->h_dc->error, "merge", c);
         c->res.n_merges = c->h_dc->n_merges; c->res.n_regions = c->h_dc->n_regions;
         c->res.lambda = prm->merging == F3DS_ADAPTIVE_LAMBDA ? (c->E ? c->h_dc->lambda : __builtin_nanf("")) : c->host_lambda;
         c->prm.color_metric = prm->color_metric; c->prm.geom_metric = prm->geom_metric; c->prm.merging = prm->merging;
@@ -763,8 +784,8 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = for_frames(b, seg_supervoxels)) || (rc = flush_sync(b))) return rc;
     uint64_t maxkey = 1;
     for (f3ds_ctx* c : b.fr) {
-        if (c->h_dc->error) return c->h_dc->error;
-        if (c->h_dc->r_overflow) return F3DS_ERR_UNSUPPORTED;
+        if (c->h_dc->error) return trace_err(c->h_dc->error, "supervoxels/adjacency", c);
+        if (c->h_dc->r_overflow) return trace_err(F3DS_ERR_UNSUPPORTED, "sweeps (R chain)", c);
         c->E = c->h_dc->n_edges; c->res.n_edges = c->E; c->res.n_supervoxels = c->h_dc->n_alive;
         const uint64_t k = (uint64_t)(c->S0 + 1) * (c->S0 + 1);
         if (k > maxkey) maxkey = k;
