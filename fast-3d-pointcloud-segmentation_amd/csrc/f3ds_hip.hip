@@ -120,6 +120,7 @@ struct f3ds_ctx {
     f3ds_result res;
     bool merge_in_lds = false;
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
+    uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
     // device scratch (grow-only)
@@ -414,6 +415,7 @@ int seg_sweeps(f3ds_ctx* c) {
         if (g_inc_shift >= 0) for (uint32_t r = 0; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
         rec<d_sweep_R_pre>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t);
         for (uint32_t pass = 0; pass < F3DS_R_PASSES; ++pass) rec<d_sweep_R>(c, pass == 0 ? grid_for(V, 256) : 64u, 0u, a, a_sweep_tag(t), t, pass);
+        rec<d_sweep_R_tail>(c, 1u, 0u, a, a_sweep_tag(t), t);
         rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
         if (g_inc_shift >= 0) rec<d_claim_mark>(c, grid_for(V, 256), 0u, a, t);
         rec<d_centroid>(c, (S0 + 3u) / 4u + (S0 ? 0u : 1u), 0u, a, t);
@@ -512,7 +514,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds, bool ke
     MergeLds xl;
     merge_fits_lds(E, S0, &xl, keys_global);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
-    xl.pool_cap = (S0 + 1u) * (4u * logS + 8u);
+    xl.pool_cap = (S0 + 1u) * (4u * logS + 8u) * c->pool_mult;
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
     ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
     xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);
@@ -608,7 +610,10 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         // a frame whose merge loop re-weights more edges than its event arrays hold (huge regions of tiny supervoxels)
         // runs the stage again -- it starts from the untouched supervoxel state -- with four times the room
         bool again = false;
-        for (f3ds_ctx* c : b.fr) if (c->h_dc->ev_overflow && c->ev_mult < 16384u) { c->ev_mult *= 4u; again = true; }
+        for (f3ds_ctx* c : b.fr) {
+            if (c->h_dc->ev_overflow == 1 && c->ev_mult < 16384u) { c->ev_mult *= 4u; again = true; }
+            if (c->h_dc->ev_overflow == 2 && c->pool_mult < 64u) { c->pool_mult *= 4u; again = true; }
+        }
         if (again) {
             for (f3ds_ctx* c : b.fr) {
                 c->h_dc->error = 0; c->h_dc->ev_overflow = 0;

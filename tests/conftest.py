@@ -151,6 +151,17 @@ def gpu_ctx(P):
     ctx.close()
 
 
+def same_bits(a, b):
+    """Byte equality, except that a NaN matches a NaN: the payload / sign of a NaN produced by 0/0 differs between the
+    host (x86: 0xFFC00000) and the device (0x7FC00000) and carries no information (float arrays only)."""
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if a.dtype.kind != "f":
+        return a.tobytes() == b.tobytes()
+    an, bn = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(an, bn)) and a[~an].tobytes() == b[~bn].tobytes()
+
+
 FIXTURE_PCD = os.path.join(ROOT, "tests", "golden", "milk_cartoon_all_small_clorox.pcd")
 
 ALL_DEBUG = ["GRID", "VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_XYZ", "VOXEL_RGB", "VOXEL_NORMAL", "VOXEL_NEIGHBORS", "POINT_VOXEL", "SEED_ORIG",

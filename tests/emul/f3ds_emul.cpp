@@ -312,7 +312,8 @@ int stage_sweeps(f3ds_emul& E) {
             // like d_sweep_R: voxels whose chain is deeper than the walker's stack are retried in later passes over the memo
             std::vector<int> todo, again;
             for (int v = 0; v < V; ++v) { if (E.owner[v]) todo.push_back(v); else ownR[v] = 0u; }
-            for (int pass = 0; pass < F3DS_R_PASSES && !todo.empty(); ++pass) {
+            for (int pass = 0; !todo.empty(); ++pass) {      // (the device: F3DS_R_PASSES grid passes, then one workgroup until done)
+                const size_t before = todo.size();
                 again.clear();
                 for (int v : todo) {
                     overflow = 0;
@@ -320,8 +321,8 @@ int stage_sweeps(f3ds_emul& E) {
                     if (overflow) again.push_back(v); else ownR[v] = E.owner[v] | (r ? F3DS_OWNR_RTRUE : 0u);
                 }
                 todo.swap(again);
+                if (todo.size() == before) return F3DS_ERR_UNSUPPORTED;      // no progress: cannot happen
             }
-            if (!todo.empty()) return F3DS_ERR_UNSUPPORTED;
         }
         // claim, in place
         std::fill(done.begin(), done.end(), 0);

@@ -28,7 +28,7 @@ for it in range(n):
     rc2, elab, eres, eh = em.segment(pts, prm)
     ok = rc == rc2
     if ok and rc == 0:
-        ok = np.array_equal(olab, elab) and all(oh.get(k).tobytes() == eh.get(k).tobytes() for k in conftest.ALL_DEBUG)
+        ok = np.array_equal(olab, elab) and all(conftest.same_bits(oh.get(k), eh.get(k)) for k in conftest.ALL_DEBUG)
     if not ok:
         bad += 1
         print("MISMATCH case", it, "rc", rc, rc2, dict(kind=kind, seed=seed, w=w, h=hgt, nan=nan), kw, flush=True)
