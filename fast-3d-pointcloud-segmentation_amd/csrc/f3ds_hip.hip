@@ -193,8 +193,8 @@ thread_local double g_t_wait = 0, g_t_launch = 0;
 // F3DS_TRACE_ERR=1: say which stage refused a frame (development aid)
 static int trace_err(int code, const char* where, const f3ds_ctx* c) {
     if (code && getenv("F3DS_TRACE_ERR"))
-        fprintf(stderr, "f3ds: error %d after %s (V %u, seeds %u, edges %u, chain overflow %d, rq %u %u %u %u %u %u)\n", code, where, c->V, c->S0, c->h_dc->n_edges,
-                c->h_dc->r_overflow, c->h_dc->rq[0], c->h_dc->rq[1], c->h_dc->rq[2], c->h_dc->rq[3], c->h_dc->rq[4], c->h_dc->rq[5]);
+        fprintf(stderr, "f3ds: error %d after %s (V %u, seeds %u, edges %u, chain overflow %d, capacity flag %d)\n", code, where, c->V, c->S0, c->h_dc->n_edges,
+                c->h_dc->r_overflow, c->h_dc->ev_overflow);
     return code;
 }
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
