@@ -29,3 +29,12 @@ def test_emulation_matches_oracle_on_random_cases(P, oracle, emul):
             assert oh.get(k).tobytes() == eh.get(k).tobytes(), (it, k)
         checked += 1
     assert checked >= 10
+
+
+def test_emulation_matches_oracle_on_degenerate_clouds():
+    """tools/fuzz_clouds.py on the CPU: empty / one-point / duplicate / collinear / planar / NaN / inf / negative-z clouds."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_clouds.py"), "80", "9"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout.splitlines()[-1], r.stdout[-2000:]

@@ -375,3 +375,13 @@ def test_random_recluster_evaluation_and_batches(P, oracle):
             assert c.result.n_regions == ores.n_regions and c.result.n_voxels == ores.n_voxels
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+def test_degenerate_clouds(P):
+    """Empty / one-point / duplicate / collinear / planar / NaN / inf / negative-z clouds with random parameters
+    (tools/fuzz_clouds.py): the device path and the oracle agree on the return code and on every array."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_clouds.py"), "80", "9", "--gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout.splitlines()[-1], r.stdout[-2000:]
