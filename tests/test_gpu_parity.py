@@ -385,3 +385,39 @@ def test_degenerate_clouds(P):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_clouds.py"), "80", "9", "--gpu"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "mismatches 0" in r.stdout.splitlines()[-1], r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_cli_flags_and_directory_mode(P, oracle, tmp_path):
+    """The reference's flags map onto the same parameters as the API: -d over two files, -r, --NT, --RGB, --ML / --EQ."""
+    import subprocess
+    from golden_cases import synthetic_truth
+    exe = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd", "supervoxel_clustering")
+    d = tmp_path / "frames"; d.mkdir()
+    frames = {}
+    for name, seed in (("a", 5), ("b", 6)):
+        pts = P.synth_frame(0, seed, 160, 120, 20)
+        truth = synthetic_truth(pts) % 7
+        P.write_pcd(str(d / (name + ".pcd")), pts[:, :3], pts[:, 3].copy().view(np.uint32), truth)
+        frames[name] = P.read_pcd(str(d / (name + ".pcd")), with_labels=True)
+    combos = [
+        (["--NT", "--RGB", "--ML", "0.3", "-t", "0.25", "-v", "0.02", "-s", "0.2", "-c", "0.5", "-z", "0.3", "-n", "2.0"],
+         dict(use_transform=0, color_metric=1, geom_metric=0, merging=0, lambda_=0.3, threshold=0.25, voxel_res=0.02, seed_res=0.2, w_color=0.5, w_spatial=0.3, w_normal=2.0), None),
+        (["--CVX", "--EQ", "50", "-t", "0.5", "-v", "0.02", "-s", "0.2"],
+         dict(geom_metric=1, merging=2, bins=50, threshold=0.5, voxel_res=0.02, seed_res=0.2), None),
+        (["--CVX", "--AL", "-t", "0.2", "-v", "0.02", "-s", "0.2", "-r", "3"], dict(threshold=0.2, voxel_res=0.02, seed_res=0.2), 3),
+    ]
+    for flags, kw, removed in combos:
+        lab = str(tmp_path / "lab")
+        r = subprocess.run([exe, "-d", str(d)] + flags + ["--labels", lab, "-f", "res"], capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        assert "Found 2 files" in r.stdout and "Average scores" in r.stdout
+        prm = P.default_params(**dict(dict(color_metric=0, geom_metric=0, merging=1), **kw)); prm.fold_negative_z = 1
+        for name, (pts, truth) in frames.items():
+            if removed is not None:                           # main():332-336: drop the label and the NaN points
+                keep = (truth != removed) & ~np.isnan(pts[:, 2])
+                pts = pts[keep]
+            rc, olab, _, _ = oracle.segment(pts, prm)
+            assert rc == 0 and np.array_equal(np.fromfile(lab + "." + name, np.uint32), olab), (flags, name)
+    r = subprocess.run([exe, "-p", str(d / "a.pcd"), "--ML", "--AL"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "Only one parameter" in r.stderr
