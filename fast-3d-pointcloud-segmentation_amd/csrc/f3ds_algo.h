@@ -164,6 +164,8 @@ F3DS_HD float a_helper_dist_row(const SweepView& s, uint32_t g, const float vrow
     return n_voxel_distance(hrow, vrow, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
 }
 #define F3DS_R_STACK 24
+#define F3DS_R_ROUNDS 3        // rounds of the incremental R pass (dirty tiles): two do the work on every frame seen so far, a change
+                               // in the last one sends the sweep to the chain walker instead
 #define F3DS_R_PASSES 1        // grid passes of the chain walker; what is still unsettled goes to the single-workgroup tail
 #define F3DS_R_TRUE 1
 #define F3DS_R_FALSE 2

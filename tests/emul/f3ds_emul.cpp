@@ -244,7 +244,7 @@ int stage_sweeps(f3ds_emul& E) {
     const int shift = env ? atoi(env) : 6;
     const uint32_t T = (uint32_t)(V + 63) / 64u;
     const uint32_t thr = shift >= 32 ? 0xFFFFFFFFu : (shift < 0 ? 0u : (uint32_t)V >> shift);
-    const int ROUNDS = 4;
+    const int ROUNDS = F3DS_R_ROUNDS;
     std::vector<uint32_t> tR[2] = {std::vector<uint32_t>(T, 0u), std::vector<uint32_t>(T, 0u)}, tC[2] = {std::vector<uint32_t>(T, 0u), std::vector<uint32_t>(T, 0u)};
     std::vector<std::vector<uint32_t>> tRr(ROUNDS, std::vector<uint32_t>(T, 0u));
     std::vector<uint32_t> hD(S0 + 1, 0u);
@@ -278,6 +278,7 @@ int stage_sweeps(f3ds_emul& E) {
                     const uint32_t nw = E.owner[v] | (a_eval_R_step(s, snap.data(), v) ? F3DS_OWNR_RTRUE : 0u);
                     if (nw != snap[v]) writes.push_back({v, nw});
                 }
+                if (getenv("F3DS_EMUL_SWEEP_STATS")) fprintf(stderr, "   sweep %u round %d: %zu words changed\n", t, r, writes.size());
                 for (auto& w : writes) {
                     ownR[w.first] = w.second;
                     mark(w.first, last ? tC[t & 1u] : tRr[r], tC[t & 1u], stamp);
