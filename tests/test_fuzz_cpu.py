@@ -31,7 +31,7 @@ def test_emulation_matches_oracle_on_random_cases(P, oracle, emul):
     assert checked >= 10
 
 
-def test_emulation_matches_oracle_on_degenerate_clouds():
+def test_emulation_matches_oracle_on_degenerate_clouds(oracle, emul):       # (the fixtures build the two libraries if needed)
     """tools/fuzz_clouds.py on the CPU: empty / one-point / duplicate / collinear / planar / NaN / inf / negative-z clouds."""
     import os, subprocess, sys
     from conftest import ROOT

@@ -378,7 +378,7 @@ def test_random_recluster_evaluation_and_batches(P, oracle):
 
 
 @pytest.mark.gpu
-def test_degenerate_clouds(P):
+def test_degenerate_clouds(P, oracle):
     """Empty / one-point / duplicate / collinear / planar / NaN / inf / negative-z clouds with random parameters
     (tools/fuzz_clouds.py): the device path and the oracle agree on the return code and on every array."""
     import subprocess, sys
