@@ -121,6 +121,7 @@ struct f3ds_ctx {
     bool merge_in_lds = false;
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
+    int idxbits = -1;                  // >= 0: the sorted point keys carry the point index in their low bits
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
     // device scratch (grow-only)
@@ -275,8 +276,8 @@ int scan_u32(f3ds_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
     return F3DS_OK;
 }
 // stable sort of (key,val) pairs on the low `total_bits` bits (the same for every frame of a batch)
-int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint32_t n, int total_bits, uint64_t** keys_out, uint32_t** vals_out) {
-    *keys_out = k0; *vals_out = v0;
+int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint32_t n, int total_bits, uint64_t** keys_out, uint32_t** vals_out, int base_shift = 0) {
+    *keys_out = k0; if (vals_out) *vals_out = v0;
     if (total_bits <= 0) return F3DS_OK;
     const int passes = (total_bits + 7) / 8;
     const int per = (total_bits + passes - 1) / passes;
@@ -286,13 +287,14 @@ int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* 
     int shift = 0;
     for (int p = 0; p < passes; ++p) {
         const int bits = (total_bits - shift) < per ? (total_bits - shift) : per;
-        rec<d_radix_hist>(c, nb, 0u, (const uint64_t*)k0, n, shift, bits, hist, nb);
+        rec<d_radix_hist>(c, nb, 0u, (const uint64_t*)k0, n, base_shift + shift, bits, hist, nb);
         rec<d_scan_single>(c, 1u, 0u, hist, (uint32_t)((1u << bits) * nb));
-        rec<d_radix_scatter>(c, nb, 0u, (const uint64_t*)k0, (const uint32_t*)v0, k1, v1, n, shift, bits, (const uint32_t*)hist, nb);
+        if (v0) rec<d_radix_scatter>(c, nb, 0u, (const uint64_t*)k0, (const uint32_t*)v0, k1, v1, n, base_shift + shift, bits, (const uint32_t*)hist, nb);
+        else rec<d_radix_scatter_k>(c, nb, 0u, (const uint64_t*)k0, k1, n, base_shift + shift, bits, (const uint32_t*)hist, nb);      // payload in the key's low bits
         std::swap(k0, k1); std::swap(v0, v1);
         shift += bits;
     }
-    *keys_out = k0; *vals_out = v0;
+    *keys_out = k0; if (vals_out) *vals_out = v0;
     return F3DS_OK;
 }
 
@@ -305,19 +307,23 @@ int seg_bbox(f3ds_ctx* c) {
     return F3DS_OK;
 }
 // stage 0b: Morton keys, stable sort, voxel segments
-int seg_sort(f3ds_ctx* c, int sort_bits) {
+int seg_sort(f3ds_ctx* c, int sort_bits, int idxbits) {      // idxbits >= 0: (code << idxbits) | index in one array; -1: (key, index) pairs
     const uint32_t n = c->n;
-    uint64_t *k0, *k1; uint32_t *v0, *v1, *flags, *incl, *seg_start; int* pt_voxel;
-    ENSURE(c->keys0, uint64_t, n, k0); ENSURE(c->keys1, uint64_t, n, k1); ENSURE(c->vals0, uint32_t, n, v0); ENSURE(c->vals1, uint32_t, n, v1);
+    uint64_t *k0, *k1; uint32_t *v0 = nullptr, *v1 = nullptr, *flags, *incl, *seg_start; int* pt_voxel;
+    ENSURE(c->keys0, uint64_t, n, k0); ENSURE(c->keys1, uint64_t, n, k1);
+    if (idxbits < 0) { ENSURE(c->vals0, uint32_t, n, v0); ENSURE(c->vals1, uint32_t, n, v1); }
     ENSURE(c->flags, uint32_t, n, flags); ENSURE(c->incl, uint32_t, n, incl); ENSURE(c->seg_start, uint32_t, (size_t)n + 1, seg_start);
     ENSURE(c->pt_voxel, int, n, pt_voxel);
-    rec<d_keys>(c, grid_for(n, 256), 0u, c->d_pts, n, c->fa, (const GridInfo*)c->d_grid, k0, v0);
-    int rc = radix_sort(c, k0, v0, k1, v1, n, sort_bits, &c->ks, &c->vs);
+    c->idxbits = idxbits;
+    const int ks = idxbits < 0 ? 0 : idxbits;
+    rec<d_keys>(c, grid_for(n, 256), 0u, c->d_pts, n, c->fa, (const GridInfo*)c->d_grid, k0, v0, ks);
+    c->vs = nullptr;
+    int rc = radix_sort(c, k0, v0, k1, v1, n, sort_bits, &c->ks, &c->vs, ks);
     if (rc) return rc;
     const uint64_t invalid = 1ull << (3 * c->h_dc->depth);
-    rec<d_heads>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, n, invalid, flags);
+    rec<d_heads>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, n, invalid, flags, ks);
     if ((rc = scan_u32(c, flags, incl, n))) return rc;
-    rec<d_segstart>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, (const uint32_t*)flags, (const uint32_t*)incl, n, invalid, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid);
+    rec<d_segstart>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, (const uint32_t*)flags, (const uint32_t*)incl, n, invalid, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid, ks);
     return F3DS_OK;
 }
 // stage 0c + 1 + 2a: voxel sums, neighbour tables, normals, seed grid growth
@@ -330,8 +336,8 @@ int seg_voxels(f3ds_ctx* c) {
     ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hcap, hkeys); ENSURE(c->hvals, uint32_t, hcap, hvals);
     P16* spts; ENSURE(c->spts, P16, n, spts);
     rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hcap * 8);
-    rec<d_point_gather>(c, grid_for(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
-    rec<d_voxel_accum>(c, grid_for(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
+    rec<d_point_gather>(c, grid_for(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
+    rec<d_voxel_accum>(c, grid_for(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
                        (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask);
     rec<d_neighbors>(c, grid_for((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                      c->hmask, nbr, nbrT);
@@ -345,15 +351,16 @@ int seg_voxels(f3ds_ctx* c) {
 // stage 2b: seed cells (sort voxels by cell)
 int seg_seed_cells(f3ds_ctx* c, int sort_bits, int max_sdepth) {
     const uint32_t V = c->V;
-    uint32_t *ckey, *cell_start; uint64_t *k0 = (uint64_t*)c->keys0.p, *k1 = (uint64_t*)c->keys1.p; uint32_t *v0 = (uint32_t*)c->vals0.p, *v1 = (uint32_t*)c->vals1.p;
+    uint32_t *ckey, *cell_start, *v0, *v1; uint64_t *k0 = (uint64_t*)c->keys0.p, *k1 = (uint64_t*)c->keys1.p;
+    ENSURE(c->vals0, uint32_t, V, v0); ENSURE(c->vals1, uint32_t, V, v1);
     ENSURE(c->ckey, uint32_t, (size_t)V * 3, ckey); ENSURE(c->cell_start, uint32_t, (size_t)V + 1, cell_start);
     rec<d_seed_keys>(c, grid_for(V, 256), 0u, (const float*)c->vf.p, (const DevCounters*)c->d_dc, (const SeedGrid*)c->d_sgrid, ckey, k0, v0);
     int rc = radix_sort(c, k0, v0, k1, v1, V, sort_bits, &c->cks, &c->cvs);
     if (rc) return rc;
     const uint64_t climit = max_sdepth >= 21 ? 0xFFFFFFFFFFFFFFFFull : (1ull << (3 * max_sdepth));
-    rec<d_heads>(c, grid_for(V, 256), 0u, (const uint64_t*)c->cks, V, climit, (uint32_t*)c->flags.p);
+    rec<d_heads>(c, grid_for(V, 256), 0u, (const uint64_t*)c->cks, V, climit, (uint32_t*)c->flags.p, 0);
     if ((rc = scan_u32(c, (const uint32_t*)c->flags.p, (uint32_t*)c->incl.p, V))) return rc;
-    rec<d_segstart>(c, grid_for(V, 256), 0u, (const uint64_t*)c->cks, (const uint32_t*)c->flags.p, (const uint32_t*)c->incl.p, V, climit, cell_start, &c->d_dc->n_cells, &c->d_dc->seg_count);
+    rec<d_segstart>(c, grid_for(V, 256), 0u, (const uint64_t*)c->cks, (const uint32_t*)c->flags.p, (const uint32_t*)c->incl.p, V, climit, cell_start, &c->d_dc->n_cells, &c->d_dc->seg_count, 0);
     return F3DS_OK;
 }
 // stage 2c: nearest voxel per cell, radius filter, kept seeds
@@ -766,7 +773,12 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = drop_dead([](f3ds_ctx* c) { return c->h_dc->grid_empty || c->n == 0; }))) return rc;
     int maxd = 0;
     for (f3ds_ctx* c : b.fr) if (c->h_dc->depth > maxd) maxd = c->h_dc->depth;
-    if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_sort(c, 3 * maxd + 1); })) || (rc = flush_sync(b))) return rc;
+    // (Morton code << idxbits) | point index in one 64-bit word when both fit: the sort then moves 8 bytes per point and pass, not 12
+    uint32_t maxn = 1;
+    for (f3ds_ctx* c : b.fr) if (c->n > maxn) maxn = c->n;
+    int idxbits = bits_for((uint64_t)maxn - 1u);
+    if (3 * maxd + 1 + idxbits > 64 || getenv("F3DS_SORT_PAIRS")) idxbits = -1;
+    if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_sort(c, 3 * maxd + 1, idxbits); })) || (rc = flush_sync(b))) return rc;
     for (f3ds_ctx* c : b.fr) { c->V = c->h_dc->n_voxels; c->res.n_voxels = c->V; }
     if ((rc = drop_dead([](f3ds_ctx* c) { return c->V == 0; }))) return rc;
     stage_mark(b, 1);
