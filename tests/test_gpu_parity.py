@@ -55,6 +55,21 @@ def test_global_memory_merge_kernel_matches_too(P, oracle, monkeypatch):
     ctx.close()
 
 
+def test_point_sort_with_key_index_pairs_matches_too(P, oracle, monkeypatch):
+    """The point sort packs (Morton code, point index) into one 64-bit word when both fit; the (key, index) pair path
+    that takes over when they do not is forced here through F3DS_SORT_PAIRS (read per call)."""
+    monkeypatch.setenv("F3DS_SORT_PAIRS", "1")
+    ctx = P.Context(0)
+    for name in ("rgbd_320x240_ghosts", "fixture_launch_flags", "rgbd_160x120_equalization"):
+        pts = case_points(P, name); prm = case_params(P, name)
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        glab = ctx.segment(pts, prm)
+        assert np.array_equal(olab, glab)
+        for what in ("VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_XYZ", "VOXEL_RGB", "POINT_VOXEL"):
+            assert not first_mismatch(what, oh.get(what), ctx.debug(what))
+    ctx.close()
+
+
 def test_recluster_and_clustering_mirror(P, oracle, gpu_ctx):
     """Clustering::cluster(threshold) again on the same supervoxels, with other metrics."""
     pts = case_points(P, "rgbd_160x120")
