@@ -120,6 +120,15 @@ def load_library(path=None):
     lib.f3ds_get_supervoxel_adjacency.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_supervoxel_adjacency.restype = ctypes.c_int
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
     lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
+    lib.f3ds_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_stream_create.restype = ctypes.c_int
+    lib.f3ds_stream_destroy.argtypes = [vp]; lib.f3ds_stream_destroy.restype = None
+    lib.f3ds_stream_buffer.argtypes = [vp, sz, ctypes.POINTER(vp)]; lib.f3ds_stream_buffer.restype = ctypes.c_int
+    lib.f3ds_stream_submit.argtypes = [vp, vp, sz, ctypes.POINTER(Params), ctypes.c_uint64]; lib.f3ds_stream_submit.restype = ctypes.c_int
+    lib.f3ds_stream_next.argtypes = [vp, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Result), ctypes.c_int]
+    lib.f3ds_stream_next.restype = ctypes.c_int
+    lib.f3ds_stream_peek.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Result), ctypes.c_int]
+    lib.f3ds_stream_peek.restype = ctypes.c_int
+    lib.f3ds_stream_pending.argtypes = [vp]; lib.f3ds_stream_pending.restype = ctypes.c_int
     lib.f3ds_pcd_read.argtypes = [ctypes.c_char_p, vp, vp, sz, ctypes.POINTER(sz), u32p, u32p]; lib.f3ds_pcd_read.restype = ctypes.c_int
     lib.f3ds_pcd_write.argtypes = [ctypes.c_char_p, vp, vp, vp, sz, ctypes.c_int]; lib.f3ds_pcd_write.restype = ctypes.c_int
     lib.f3ds_synth_frame.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp]
@@ -131,7 +140,7 @@ def load_library(path=None):
 
 
 (OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_DEPTH, ERR_LOGIC, ERR_RANGE, ERR_UNSUPPORTED, ERR_IO, ERR_EQ_BIN,
- ERR_CAPACITY) = (0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10)       # include/f3ds.h:37-50
+ ERR_CAPACITY, ERR_BUSY, ERR_EMPTY) = (0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11, -12)       # include/f3ds.h:37-52
 
 
 def _check(lib, rc):
@@ -317,6 +326,95 @@ class Context:
         buf = np.zeros(nb.value, np.uint8)
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, DBG[name], buf.ctypes.data, nb.value, ctypes.byref(nb)))
         return buf.view(DBG_DTYPE[name])
+
+
+class FrameStream:
+    """Frame pipeline (f3ds_stream_*): frames in from host memory, per-point labels out in submission order, up to
+    ``depth`` frames in flight on ``groups`` host threads.  ``submit`` returns False instead of blocking when the
+    pipeline is full; ``next`` returns (tag, labels, Result) of the oldest frame, None when nothing is in flight."""
+
+    def __init__(self, device=0, depth=8, groups=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.f3ds_stream_create(device, depth, groups, ctypes.byref(h)))
+        self.handle = h
+        self.depth = depth
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.f3ds_stream_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def pending(self):
+        return self.lib.f3ds_stream_pending(self.handle)
+
+    def buffer(self, n):
+        """(n,4) float32 view of the pinned input buffer the next submit uses, or None when the pipeline is full."""
+        p = ctypes.c_void_p()
+        rc = self.lib.f3ds_stream_buffer(self.handle, n, ctypes.byref(p))
+        if rc == ERR_BUSY:
+            return None
+        _check(self.lib, rc)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), shape=(max(n, 1), 4))[:n]
+
+    def submit(self, points, params, tag=0):
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
+        rc = self.lib.f3ds_stream_submit(self.handle, pts.ctypes.data, len(pts), ctypes.byref(params), tag)
+        if rc == ERR_BUSY:
+            return False
+        _check(self.lib, rc)
+        return True
+
+    def next(self, wait=True):
+        n = ctypes.c_size_t(); tag = ctypes.c_uint64(); res = Result()
+        probe = np.empty(1, np.uint32)
+        rc = self.lib.f3ds_stream_next(self.handle, probe.ctypes.data, 0, ctypes.byref(n), ctypes.byref(tag), ctypes.byref(res), 1 if wait else 0)
+        if rc in (ERR_EMPTY, ERR_BUSY):
+            return None
+        labels = np.empty(n.value, np.uint32)
+        if rc == ERR_CAPACITY:                              # the frame is done and still there: now with room for its labels
+            rc = self.lib.f3ds_stream_next(self.handle, labels.ctypes.data, len(labels), ctypes.byref(n), ctypes.byref(tag), ctypes.byref(res), 1)
+        _check(self.lib, rc)
+        return tag.value, labels, res
+
+    def peek(self, wait=True):
+        """(tag, labels, Result) of the oldest frame without copying: ``labels`` is a view of the slot's pinned buffer,
+        valid until ``drop()``.  None when nothing is in flight (or, with wait=False, not done yet)."""
+        n = ctypes.c_size_t(); tag = ctypes.c_uint64(); res = Result(); p = ctypes.c_void_p()
+        rc = self.lib.f3ds_stream_peek(self.handle, ctypes.byref(p), ctypes.byref(n), ctypes.byref(tag), ctypes.byref(res), 1 if wait else 0)
+        if rc in (ERR_EMPTY, ERR_BUSY):
+            return None
+        _check(self.lib, rc)
+        lab = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint32)), shape=(max(n.value, 1),))[:n.value]
+        return tag.value, lab, res
+
+    def drop(self):
+        """Take the oldest (finished) frame out of the pipeline without copying its labels."""
+        rc = self.lib.f3ds_stream_next(self.handle, None, 0, None, None, None, 1)
+        if rc != ERR_EMPTY:
+            _check(self.lib, rc)
+
+    def run(self, frames, params):
+        """Generator: feed an iterable of (N,4) frames, yield (index, labels, Result) in order."""
+        i = 0
+        for pts in frames:
+            while not self.submit(pts, params, i):
+                yield self.next()
+            i += 1
+        while self.pending():
+            yield self.next()
 
 
 def segment_batch(ctxs, points, params, labels_out=None, n=None, on_device=False):

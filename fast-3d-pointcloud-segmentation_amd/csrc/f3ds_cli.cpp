@@ -4,7 +4,8 @@
 //
 // Kept from the reference: -d/-p, -v -s -c -z -n, -t, --RGB --CVX --ML --AL --EQ, -r, -f, --NT, --V.
 // Added (additive): -o <pcd> coloured voxel cloud (Clustering::get_colored_cloud), --labels <file>
-// per-point uint32 region ids, --gpu <id>.  Without -t the threshold is chosen by the ground-truth sweep
+// per-point uint32 region ids, --gpu <id>, --stream <depth> (label files only: the files go through the frame
+// pipeline f3ds_stream_*, reading ahead of the GPU, no evaluation).  Without -t the threshold is chosen by the ground-truth sweep
 // (all_thresh 0.8..1 step 0.005 + best_thresh, :428-437) and the <-f name>_*.csv score files are written
 // (:471, manageAllPerformances); every file is scored against its `label` field (:462-463).
 #include <cmath>
@@ -66,7 +67,8 @@ int main(int argc, char** argv) {
                " --V                            (verbose) \n\t"
                " -o <out.pcd>                   (writes the coloured voxel cloud) \n\t"
                " --labels <file>                (writes per-point uint32 region ids) \n\t"
-               " --gpu <id>                     (HIP device, default 0) \n",
+               " --gpu <id>                     (HIP device, default 0) \n\t"
+               " --stream <depth>               (with -t and --labels: files through the frame pipeline, <depth> in flight) \n",
                argv[0]);
         return 1;
     }
@@ -122,6 +124,46 @@ int main(int argc, char** argv) {
     prm.geom_metric = cvx ? F3DS_CONVEX_NORMALS_DIFF : F3DS_NORMALS_DIFF;
     prm.merging = ml ? F3DS_MANUAL_LAMBDA : (eq ? F3DS_EQUALIZATION : F3DS_ADAPTIVE_LAMBDA);
     prm.lambda = lambda; prm.bins = bin_num; prm.threshold = thresh; prm.fold_negative_z = 1;
+    int stream_depth = 0;
+    if (find_switch(argc, argv, "--stream")) parse(argc, argv, "--stream", stream_depth);
+    if (stream_depth > 0) {
+        // Streaming mode: what a ROS node around this path would do (README.md:72) -- frames in, per-point labels out, in
+        // order; file k+1 is read (into the pinned slot) while the GPU works on file k.  No ground-truth sweep or scores here.
+        if (!thresh_specified || out_labels.empty() || remove_label) { fprintf(stderr, "--stream needs -t <threshold> and --labels <file>, and does not take -r\n"); return 1; }
+        f3ds_stream* fs = nullptr;
+        int rc = f3ds_stream_create(gpu, stream_depth, 0, &fs);
+        if (rc) { fprintf(stderr, "f3ds_stream_create: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); return 1; }
+        int failed = 0;
+        auto take = [&](int wait) -> bool {                    // one finished frame -> its label file
+            size_t n = 0; uint64_t tag = 0; f3ds_result res;
+            static std::vector<uint32_t> labels;
+            uint32_t probe;
+            int r = f3ds_stream_next(fs, &probe, 0, &n, &tag, &res, wait);
+            if (r == F3DS_ERR_EMPTY || r == F3DS_ERR_BUSY) return false;
+            if (r == F3DS_ERR_CAPACITY) { labels.resize(n); r = f3ds_stream_next(fs, labels.data(), n, &n, &tag, &res, 1); }
+            const std::string& file = file_list[tag];
+            if (r) { fprintf(stderr, "%s: %s\n", file.c_str(), f3ds_strerror(r)); failed = 1; return true; }
+            std::string suffix = file_list.size() > 1 ? "." + std::filesystem::path(file).stem().string() : "";
+            FILE* f = fopen((out_labels + suffix).c_str(), "wb");
+            if (!f || fwrite(labels.data(), 4, n, f) != n) { fprintf(stderr, "writing %s failed\n", (out_labels + suffix).c_str()); failed = 1; }
+            if (f) fclose(f);
+            printf("%s: %llu points, %u voxels, %u supervoxels, %u merges -> %u regions\n", file.c_str(), (unsigned long long)res.n_points, res.n_voxels,
+                   res.n_supervoxels, res.n_merges, res.n_regions);
+            return true;
+        };
+        for (size_t k = 0; k < file_list.size(); ++k) {
+            size_t n = 0; void* buf = nullptr;
+            if (f3ds_pcd_read(file_list[k].c_str(), nullptr, nullptr, 0, &n, nullptr, nullptr) != F3DS_OK) n = 0;
+            while ((rc = f3ds_stream_buffer(fs, n, &buf)) == F3DS_ERR_BUSY) take(1);
+            if (rc) { fprintf(stderr, "f3ds_stream_buffer: %s\n", f3ds_strerror(rc)); failed = 1; break; }
+            if (n && f3ds_pcd_read(file_list[k].c_str(), buf, nullptr, n, &n, nullptr, nullptr) != F3DS_OK) n = 0;      // straight into pinned memory
+            if ((rc = f3ds_stream_submit(fs, buf, n, &prm, k))) { fprintf(stderr, "f3ds_stream_submit: %s\n", f3ds_strerror(rc)); failed = 1; break; }
+            while (take(0)) {}
+        }
+        while (f3ds_stream_pending(fs) > 0) take(1);
+        f3ds_stream_destroy(fs);
+        return failed;
+    }
     f3ds_ctx* ctx = nullptr;
     int rc = f3ds_create(gpu, &ctx);
     if (rc) { fprintf(stderr, "f3ds_create: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); return 1; }

@@ -51,6 +51,8 @@ const char* f3ds_strerror(int code) {
         case F3DS_ERR_IO: return "PCD file i/o error";
         case F3DS_ERR_EQ_BIN: return "equalization bin out of range (delta == 1.0 under --EQ)";
         case F3DS_ERR_CAPACITY: return "output buffer too small";
+        case F3DS_ERR_BUSY: return "frame pipeline busy";
+        case F3DS_ERR_EMPTY: return "frame pipeline empty";
     }
     return "unknown error";
 }

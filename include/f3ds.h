@@ -48,6 +48,8 @@ extern "C" {
 #define F3DS_ERR_EQ_BIN (-9)       /* --EQ with delta_g == 1.0: map::at throws in the reference
                                       (src/clustering.cpp:371-372, t_g has no clamp)            */
 #define F3DS_ERR_CAPACITY (-10)    /* output buffer too small                                   */
+#define F3DS_ERR_BUSY (-11)        /* frame pipeline: every slot in flight / oldest frame not done yet */
+#define F3DS_ERR_EMPTY (-12)       /* frame pipeline: nothing submitted that has not been taken */
 
 /* enums mirror include/supervoxel_clustering/clustering.h:58-68 */
 enum { F3DS_LAB_CIEDE00 = 0, F3DS_RGB_EUCL = 1 };
@@ -198,6 +200,35 @@ int f3ds_auto_threshold(f3ds_ctx* ctx, const f3ds_params* params, const uint32_t
                         float start, float end, float step, float* thresholds, f3ds_performance* scores,
                         size_t cap, size_t* n_out, float* best_threshold, f3ds_performance* best_score,
                         uint32_t* point_labels, int labels_on_device, f3ds_result* result);
+
+/* ---- frame pipeline (row N4: the streaming surface the reference's ROS launch file points at,
+ * launch/supervoxel_clustering.launch:3-6, README.md:72) ----------------------------------------
+ * Frames go in from host memory one at a time and come out in submission order.  Up to `depth`
+ * frames are in flight: each has a context and pinned staging for its points and labels, `groups`
+ * host threads pick up whatever is queued -- one frame when the producer is slow (latency of a lone
+ * frame), a run of consecutive frames with equal parameters as one f3ds_segment_batch when frames
+ * arrive faster than they finish (throughput of the batched path) -- so H2D of one group overlaps
+ * the kernels and the merge loop of the others.  Results per frame are those of f3ds_segment.
+ * submit/next may be called from different threads (one producer, one consumer). */
+typedef struct f3ds_stream f3ds_stream;
+int f3ds_stream_create(int device, int depth, int groups, f3ds_stream** out);
+void f3ds_stream_destroy(f3ds_stream* s);
+/* pinned input buffer of the slot the next submit will use, sized for n points; filling it in place
+ * (e.g. f3ds_pcd_read straight into it) saves submit's copy.  F3DS_ERR_BUSY when depth frames are in flight. */
+int f3ds_stream_buffer(f3ds_stream* s, size_t n, void** points16);
+/* queue a frame (host memory; copied unless it is the pointer f3ds_stream_buffer gave).  Never blocks:
+ * F3DS_ERR_BUSY when depth frames are in flight -- take one with f3ds_stream_next first. */
+int f3ds_stream_submit(f3ds_stream* s, const void* points, size_t n, const f3ds_params* params, uint64_t tag);
+/* oldest frame not taken yet: its labels (n_out of them) into point_labels, its tag and result.  wait != 0 blocks
+ * until it is done, else F3DS_ERR_BUSY while it is running; F3DS_ERR_EMPTY when nothing is in flight;
+ * F3DS_ERR_CAPACITY (frame stays) when cap < its point count; n_out and tag are set in all three cases but EMPTY.
+ * Otherwise the frame leaves the pipeline and the call returns the frame's own status. */
+int f3ds_stream_next(f3ds_stream* s, uint32_t* point_labels, size_t cap, size_t* n_out, uint64_t* tag, f3ds_result* result, int wait);
+/* the oldest frame's labels where they are (the slot's pinned buffer) instead of a copy: valid until the frame is
+ * taken with f3ds_stream_next(s, NULL, 0, ...).  Same waiting rule and return values as f3ds_stream_next. */
+int f3ds_stream_peek(f3ds_stream* s, const uint32_t** point_labels, size_t* n_out, uint64_t* tag, f3ds_result* result, int wait);
+/* frames submitted and not taken */
+int f3ds_stream_pending(f3ds_stream* s);
 
 /* ---- host-side helpers either side of the path (no GPU needed) -------------------------- */
 

@@ -31,7 +31,7 @@ def test_struct_layout_matches_header(P):
 
 def test_error_strings(P):
     lib = P.load_library()
-    for code in range(0, -11, -1):
+    for code in range(0, -13, -1):
         assert lib.f3ds_strerror(code).decode() != "unknown error"
     assert lib.f3ds_strerror(-99).decode() == "unknown error"
     assert "Cannot call 'cluster'" in lib.f3ds_strerror(-5).decode()
@@ -43,6 +43,22 @@ def test_no_cpu_fallback(P):
     with pytest.raises(P.F3dsError) as e:
         P.Context(0)
     assert e.value.code == -2
+
+
+def test_frame_pipeline_argument_checks_need_no_gpu(P):
+    lib = P.load_library()
+    h = ctypes.c_void_p()
+    assert lib.f3ds_stream_create(0, 0, 0, ctypes.byref(h)) == P.ERR_ARG and not h.value
+    assert lib.f3ds_stream_create(0, 4, -1, ctypes.byref(h)) == P.ERR_ARG
+    assert lib.f3ds_stream_create(0, 4, 0, None) == P.ERR_ARG
+    prm = P.default_params()
+    assert lib.f3ds_stream_submit(None, None, 0, ctypes.byref(prm), 0) == P.ERR_ARG
+    assert lib.f3ds_stream_next(None, None, 0, None, None, None, 0) == P.ERR_ARG and lib.f3ds_stream_pending(None) == P.ERR_ARG
+    lib.f3ds_stream_destroy(None)
+    if P.device_count() == 0:
+        with pytest.raises(P.F3dsError) as e:
+            P.FrameStream(0, depth=2)
+        assert e.value.code == P.ERR_NO_DEVICE
 
 
 def test_pcd_roundtrip_all_modes(P, tmp_path):

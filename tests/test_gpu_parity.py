@@ -436,3 +436,114 @@ def test_cli_flags_and_directory_mode(P, oracle, tmp_path):
             assert rc == 0 and np.array_equal(np.fromfile(lab + "." + name, np.uint32), olab), (flags, name)
     r = subprocess.run([exe, "-p", str(d / "a.pcd"), "--ML", "--AL"], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "Only one parameter" in r.stderr
+    # --stream: the same files through the frame pipeline, label files only
+    lab = str(tmp_path / "slab")
+    r = subprocess.run([exe, "-d", str(d), "--CVX", "--AL", "-t", "0.2", "-v", "0.02", "-s", "0.2", "--labels", lab, "--stream", "2"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    prm = P.launch_params(voxel_res=0.02, seed_res=0.2); prm.fold_negative_z = 1
+    for name, (pts, truth) in frames.items():
+        rc, olab, ores, _ = oracle.segment(pts, prm)
+        assert np.array_equal(np.fromfile(lab + "." + name, np.uint32), olab), name
+        assert "%s.pcd: %d points, %d voxels" % (name, len(pts), ores.n_voxels) in r.stdout
+    r = subprocess.run([exe, "-d", str(d), "--stream", "2", "--labels", lab], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "--stream needs -t" in r.stderr
+
+
+def test_frame_pipeline_returns_every_frame_in_order_with_the_labels_of_single_calls(P, oracle, gpu_ctx):
+    """Row N4 (f3ds_stream_*): frames of different sizes and two parameter sets through a pipeline of depth 4 with two
+    worker threads; tags come back in submission order, labels and counts are those of f3ds_segment on the same
+    frame, which the oracle checks for a few of them."""
+    frames = [P.synth_frame(0, 4000 + i, 96 + 16 * (i % 3), 72 + 8 * (i % 2), 25) for i in range(11)]
+    frames[4] = np.zeros((0, 4), np.float32)                     # an empty frame in the middle
+    frames[7] = np.full((50, 4), np.float32("nan"))              # and one without a finite point
+    prms = [P.launch_params(voxel_res=0.02, seed_res=0.2), P.launch_params(voxel_res=0.03, seed_res=0.2, threshold=0.3)]
+    pick = lambda i: prms[1 if i in (2, 3, 8) else 0]
+    want = []
+    for i, f in enumerate(frames):
+        lab = gpu_ctx.segment(f, pick(i))
+        want.append((lab, gpu_ctx.result.n_voxels, gpu_ctx.result.n_regions))
+    for i in (0, 3, 10):
+        rc, olab, ores, _ = oracle.segment(frames[i], pick(i))
+        assert rc == 0 and np.array_equal(olab, want[i][0])
+    with P.FrameStream(0, depth=4, groups=2) as fs:
+        assert fs.next() is None and fs.pending() == 0           # nothing in flight
+        got = []
+        i = 0
+        while i < len(frames):
+            if fs.submit(frames[i], pick(i), tag=100 + i):
+                i += 1
+            else:
+                assert fs.pending() == 4                         # full: never blocks, take the oldest
+                got.append(fs.next())
+        while fs.pending():
+            got.append(fs.next())
+        assert fs.next() is None
+    assert [g[0] for g in got] == [100 + i for i in range(len(frames))]
+    for i, (tag, lab, res) in enumerate(got):
+        assert np.array_equal(lab, want[i][0]), i
+        assert (res.n_points, res.n_voxels, res.n_regions) == (len(frames[i]), want[i][1], want[i][2]), i
+
+
+def test_frame_pipeline_buffers_capacity_and_threads(P, gpu_ctx):
+    """Zero-copy submission through the slot's pinned buffer, F3DS_ERR_CAPACITY leaves the frame in place, a frame that
+    fails (voxel grid too deep) reports its own status without disturbing its neighbours, and a producer thread
+    feeding while this thread consumes ends with every frame delivered once."""
+    import ctypes, threading, time
+    prm = P.launch_params(voxel_res=0.02, seed_res=0.2)
+    f0 = P.synth_frame(0, 5000, 128, 96, 20)
+    w0 = gpu_ctx.segment(f0, prm)
+    lib = P.load_library()
+    with P.FrameStream(0, depth=3, groups=3) as fs:
+        buf = fs.buffer(len(f0))
+        buf[:] = f0
+        assert fs.submit(buf, prm, 7)
+        n = ctypes.c_size_t(); tag = ctypes.c_uint64()
+        small = np.empty(10, np.uint32)
+        assert lib.f3ds_stream_next(fs.handle, small.ctypes.data, 10, ctypes.byref(n), ctypes.byref(tag), None, 1) == P.ERR_CAPACITY
+        assert n.value == len(f0) and tag.value == 7 and fs.pending() == 1
+        t, lab, res = fs.next()
+        assert t == 7 and np.array_equal(lab, w0)
+        assert fs.peek() is None and fs.submit(f0, prm, 8)
+        t, view, res = fs.peek()                                 # labels in place, frame still in the pipeline
+        assert t == 8 and np.array_equal(view, w0) and fs.pending() == 1 and res.n_points == len(f0)
+        fs.drop()
+        assert fs.pending() == 0
+        # a frame the device path refuses (grid deeper than 21 levels) between two good ones, same parameters: whether
+        # the worker ran them as one batch or not, each frame reports its own status
+        bad = f0.copy(); bad[0, :3] = (1e6, 1e6, 5.0)
+        assert fs.submit(f0, prm, 1) and fs.submit(bad, prm, 2) and fs.submit(f0, prm, 3)
+        assert not fs.submit(f0, prm, 4) and fs.buffer(10) is None
+        assert np.array_equal(fs.next()[1], w0)
+        with pytest.raises(P.F3dsError) as e:
+            fs.next()
+        assert e.value.code == P.ERR_DEPTH
+        assert np.array_equal(fs.next()[1], w0) and fs.pending() == 0
+    with P.FrameStream(0, depth=3, groups=1) as fs:              # one worker: the three frames can share a batch call
+        assert fs.submit(f0, prm, 1) and fs.submit(bad, prm, 2) and fs.submit(f0, prm, 3)
+        assert np.array_equal(fs.next()[1], w0)
+        with pytest.raises(P.F3dsError) as e:
+            fs.next()
+        assert e.value.code == P.ERR_DEPTH
+        assert np.array_equal(fs.next()[1], w0) and fs.pending() == 0
+    with P.FrameStream(0, depth=6, groups=2) as fs:
+        # producer / consumer
+        frames = [P.synth_frame(0, 5100 + i, 96, 72, 20) for i in range(4)]
+        wants = [gpu_ctx.segment(f, prm) for f in frames]
+        total = 24
+        def produce():
+            i = 0
+            while i < total:
+                if fs.submit(frames[i % 4], prm, i):
+                    i += 1
+                else:
+                    time.sleep(0.0005)
+        th = threading.Thread(target=produce); th.start()
+        seen = 0
+        while seen < total:
+            r = fs.next(wait=True)
+            if r is None:
+                continue
+            assert r[0] == seen and np.array_equal(r[1], wants[seen % 4]), seen
+            seen += 1
+        th.join()
+        assert fs.pending() == 0
