@@ -118,6 +118,9 @@ def load_library(path=None):
     lib.f3ds_get_voxel_centroid_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_centroid_cloud.restype = ctypes.c_int
     lib.f3ds_get_supervoxels.argtypes = [vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_supervoxels.restype = ctypes.c_int
     lib.f3ds_get_supervoxel_adjacency.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_supervoxel_adjacency.restype = ctypes.c_int
+    lib.f3ds_refine_supervoxels.argtypes = [vp, ctypes.c_int]; lib.f3ds_refine_supervoxels.restype = ctypes.c_int
+    lib.f3ds_get_refined_voxels.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_refined_voxels.restype = ctypes.c_int
+    lib.f3ds_get_refined_supervoxels.argtypes = [vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_refined_supervoxels.restype = ctypes.c_int
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
     lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
     lib.f3ds_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_stream_create.restype = ctypes.c_int
@@ -303,6 +306,22 @@ class Context:
                    n_voxels=np.zeros(k, np.uint32))
         _check(self.lib, self.lib.f3ds_get_supervoxels(self.handle, out["label"].ctypes.data, out["xyz"].ctypes.data, out["rgb"].ctypes.data, out["normal"].ctypes.data,
                                                        out["n_voxels"].ctypes.data, k, ctypes.byref(n)))
+        return out
+
+    def refine_supervoxels(self, num_itr):
+        """refineSupervoxels(num_itr): dict with per-voxel ``voxel_label`` / ``voxel_normal`` (leaf order) and the refined
+        supervoxel map ``label, xyz, rgb, normal, n_voxels``.  The frame's own supervoxels and clustering are untouched."""
+        _check(self.lib, self.lib.f3ds_refine_supervoxels(self.handle, int(num_itr)))
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_refined_voxels(self.handle, None, None, 0, ctypes.byref(n)))
+        vl = np.zeros(n.value, np.uint32); vn = np.zeros((n.value, 3), np.float32)
+        _check(self.lib, self.lib.f3ds_get_refined_voxels(self.handle, vl.ctypes.data, vn.ctypes.data, n.value, ctypes.byref(n)))
+        _check(self.lib, self.lib.f3ds_get_refined_supervoxels(self.handle, None, None, None, None, None, 0, ctypes.byref(n)))
+        k = n.value
+        out = dict(voxel_label=vl, voxel_normal=vn, label=np.zeros(k, np.uint32), xyz=np.zeros((k, 3), np.float32), rgb=np.zeros((k, 3), np.float32),
+                   normal=np.zeros((k, 3), np.float32), n_voxels=np.zeros(k, np.uint32))
+        _check(self.lib, self.lib.f3ds_get_refined_supervoxels(self.handle, out["label"].ctypes.data, out["xyz"].ctypes.data, out["rgb"].ctypes.data,
+                                                               out["normal"].ctypes.data, out["n_voxels"].ctypes.data, k, ctypes.byref(n)))
         return out
 
     def supervoxel_adjacency(self):
@@ -499,6 +518,9 @@ class SupervoxelClustering:
     def makeSupervoxelNormalCloud(self):           # :360 -> (centroid xyz, normal) per supervoxel
         sv = self.ctx.supervoxels()
         return sv["xyz"], sv["normal"]
+
+    def refineSupervoxels(self, num_itr):          # :371 -> refined per-voxel labels / normals and supervoxel map
+        return self.ctx.refine_supervoxels(num_itr)
 
     def getSupervoxelAdjacency(self):              # :365
         return self.ctx.supervoxel_adjacency()

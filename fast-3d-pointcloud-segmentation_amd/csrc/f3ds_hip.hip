@@ -121,6 +121,7 @@ struct f3ds_ctx {
     bool merge_in_lds = false;
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
+    int refined_itr = -1;              // >= 0: the r_* buffers hold the state after that many refinement iterations of this frame
     int idxbits = -1;                  // >= 0: the sorted point keys carry the point index in their low bits
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
     MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
@@ -130,6 +131,7 @@ struct f3ds_ctx {
     Buf owner0, owner1, ownR, dist0, dist1, R, hc, hcount, hlo, hhi, ghost_vox, ghost_active, ghost_done, ghost_head, ghost_next;
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
+    Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
     Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
@@ -384,19 +386,26 @@ int seg_seeds(f3ds_ctx* c) {
     return F3DS_OK;
 }
 // stage 3: helpers and all label-propagation sweeps
-int seg_sweeps(f3ds_ctx* c) {
+// The state a run of sweeps works on: extract's own (ctx members) or the copy refineSupervoxels continues from
+struct SweepBufs {
+    Buf *owner, *dist, *hc, *hcount, *hlo, *hhi, *ghost_vox, *ghost_active, *ghost_done, *ghost_head, *ghost_next, *htiles, *htcnt;
+    const float* vf;        // voxel features (refine: the copy with the refined normals)
+    const int* seeds;       // S0 seed voxels (refine: -1 for helpers erased earlier)
+    bool reseed;            // refine: centroids are kept, helpers without a seed stay empty
+};
+int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     const uint32_t V = c->V, S0 = c->S0;
     const f3ds_params& prm = c->prm;
     uint32_t *owner0, *ownR, *hcount, *hlo, *hhi, *ghost_head, *ghost_next; float *dist0, *hc; unsigned char *R, *ghost_active, *ghost_done; int* ghost_vox;
-    ENSURE(c->owner0, uint32_t, V, owner0); ENSURE(c->ownR, uint32_t, V, ownR); ENSURE(c->dist0, float, V, dist0);
-    ENSURE(c->R, unsigned char, V, R); ENSURE(c->hc, float, (size_t)(S0 + 1) * 12, hc); ENSURE(c->hcount, uint32_t, S0 + 1, hcount);
-    ENSURE(c->hlo, uint32_t, S0 + 1, hlo); ENSURE(c->hhi, uint32_t, S0 + 1, hhi); ENSURE(c->ghost_vox, int, S0 + 1, ghost_vox);
-    ENSURE(c->ghost_active, unsigned char, S0 + 1, ghost_active); ENSURE(c->ghost_done, unsigned char, S0 + 1, ghost_done);
-    ENSURE(c->ghost_head, uint32_t, V, ghost_head); ENSURE(c->ghost_next, uint32_t, S0 + 1, ghost_next);
+    ENSURE(*sb.owner, uint32_t, V, owner0); ENSURE(c->ownR, uint32_t, V, ownR); ENSURE(*sb.dist, float, V, dist0);
+    ENSURE(c->R, unsigned char, V, R); ENSURE(*sb.hc, float, (size_t)(S0 + 1) * 12, hc); ENSURE(*sb.hcount, uint32_t, S0 + 1, hcount);
+    ENSURE(*sb.hlo, uint32_t, S0 + 1, hlo); ENSURE(*sb.hhi, uint32_t, S0 + 1, hhi); ENSURE(*sb.ghost_vox, int, S0 + 1, ghost_vox);
+    ENSURE(*sb.ghost_active, unsigned char, S0 + 1, ghost_active); ENSURE(*sb.ghost_done, unsigned char, S0 + 1, ghost_done);
+    ENSURE(*sb.ghost_head, uint32_t, V, ghost_head); ENSURE(*sb.ghost_next, uint32_t, S0 + 1, ghost_next);
     const uint32_t T = (V + 63u) / 64u;
     uint32_t *tiles4, *trr, *hD;
     ENSURE(c->tstamp, uint32_t, (size_t)4 * T, tiles4); ENSURE(c->tround, uint32_t, (size_t)(F3DS_R_ROUNDS - 1) * T, trr); ENSURE(c->hdirty, uint32_t, S0 + 1, hD);
-    uint32_t *tl, *tcnt; ENSURE(c->htiles, uint32_t, (size_t)(S0 + 1) * HT_CAP, tl); ENSURE(c->htcnt, uint32_t, S0 + 1, tcnt);
+    uint32_t *tl, *tcnt; ENSURE(*sb.htiles, uint32_t, (size_t)(S0 + 1) * HT_CAP, tl); ENSURE(*sb.htcnt, uint32_t, S0 + 1, tcnt);
     uint32_t *chg, *wl, *wl2; ENSURE(c->vchg, uint32_t, V, chg); ENSURE(c->vwl, uint32_t, V, wl); ENSURE(c->vwl2, uint32_t, V, wl2);
     rec_fill(c, chg, 0u, (size_t)V * 4);
     rec_fill(c, tiles4, 0u, (size_t)4 * T * 4);
@@ -406,9 +415,14 @@ int seg_sweeps(f3ds_ctx* c) {
     rec_fill(c, ghost_head, 0u, (size_t)V * 4);
     rec_fill(c, ghost_next, 0u, (size_t)(S0 + 1) * 4);
     rec<d_fill_f32>(c, grid_for(V, 256), 0u, dist0, V, F3DS_FLT_MAX);
-    rec<d_helper_own>(c, grid_for(S0, 256), 0u, (const int*)c->seed_kept.p, S0, owner0);
-    rec<d_helper_init>(c, grid_for(S0 + 1, 256), 0u, (const int*)c->seed_kept.p, S0, (const uint32_t*)owner0, ghost_vox, ghost_active, ghost_done, hlo, hhi, hcount, hc, tl, tcnt);
-    const int* nbrT = (const int*)c->nbrT.p; const float* vf = (const float*)c->vf.p;
+    if (sb.reseed) {
+        rec<d_reseed_own>(c, grid_for(S0, 256), 0u, sb.seeds, S0, owner0);
+        rec<d_reseed_init>(c, grid_for(S0 + 1, 256), 0u, sb.seeds, S0, (const uint32_t*)owner0, ghost_vox, ghost_active, ghost_done, hlo, hhi, hcount, tl, tcnt);
+    } else {
+        rec<d_helper_own>(c, grid_for(S0, 256), 0u, sb.seeds, S0, owner0);
+        rec<d_helper_init>(c, grid_for(S0 + 1, 256), 0u, sb.seeds, S0, (const uint32_t*)owner0, ghost_vox, ghost_active, ghost_done, hlo, hhi, hcount, hc, tl, tcnt);
+    }
+    const int* nbrT = (const int*)c->nbrT.p; const float* vf = sb.vf;
     SweepFrame a;
     a.sv = SweepView{(int)V, nbrT, vf, owner0, dist0, hc, ghost_head, ghost_next, (const uint32_t*)&c->d_dc->n_ghosts, prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
     a.R = R; a.ownR = ownR; a.owner_out = owner0; a.dist_out = dist0;
@@ -429,6 +443,11 @@ int seg_sweeps(f3ds_ctx* c) {
         if (g_inc_shift >= 0) rec<d_centroid_mark>(c, (S0 + 3u) / 4u + (S0 ? 0u : 1u), 0u, a, t);
     }
     return F3DS_OK;
+}
+int seg_sweeps(f3ds_ctx* c) {
+    SweepBufs sb{&c->owner0, &c->dist0, &c->hc, &c->hcount, &c->hlo, &c->hhi, &c->ghost_vox, &c->ghost_active, &c->ghost_done, &c->ghost_head, &c->ghost_next,
+                 &c->htiles, &c->htcnt, (const float*)c->vf.p, (const int*)c->seed_kept.p, false};
+    return seg_sweeps_on(c, sb);
 }
 // stage 4a: supervoxel payload rows, adjacency set
 int seg_supervoxels(f3ds_ctx* c) {
@@ -739,7 +758,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
         c->cmds.clear(); c->blob.clear();
-        c->have_frame = false; c->live = true; c->rc = 0;
+        c->have_frame = false; c->live = true; c->rc = 0; c->refined_itr = -1;
         c->prm = *prm; c->n = (uint32_t)counts[i]; c->V = c->C = c->S0 = c->E = 0;
         memset(&c->res, 0, sizeof c->res);
         c->res.n_points = c->n; c->res.sweeps = sweeps;
@@ -915,15 +934,67 @@ extern "C" int f3ds_get_voxel_centroid_cloud(f3ds_ctx* c, float* xyz, uint32_t* 
     return F3DS_OK;
 }
 
-extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels, size_t cap, size_t* n_out) {
-    if (!c) return F3DS_ERR_ARG;
+extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels, size_t cap, size_t* n_out);
+
+// SupervoxelClustering::refineSupervoxels(num_itr, refined) [PCL-recall], called at src/supervoxel_clustering.cpp:371: on copies of
+// the sweep state (main() goes on clustering the unrefined supervoxels), num_itr x { refineNormals on every helper's leaves;
+// reseedSupervoxels; expandSupervoxels(max_depth) }.
+extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
+    if (!c || num_itr < 0) return F3DS_ERR_ARG;
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     HIPCHECK(hipSetDevice(c->device));
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    c->cmds.clear(); c->blob.clear();
+    c->refined_itr = -1;
+    const uint32_t V = c->V, S0 = c->S0;
+    float *r_vf, *r_hc; uint32_t *r_owner, *r_hcount, *L; int *r_gvox, *seed; unsigned char* r_gact;
+    ENSURE(c->r_vf, float, (size_t)V * 12, r_vf); ENSURE(c->r_owner, uint32_t, V, r_owner); ENSURE(c->r_hc, float, (size_t)(S0 + 1) * 12, r_hc);
+    ENSURE(c->r_hcount, uint32_t, S0 + 1, r_hcount); ENSURE(c->r_gvox, int, S0 + 1, r_gvox); ENSURE(c->r_gact, unsigned char, S0 + 1, r_gact);
+    ENSURE(c->r_seed, int, S0 + 1, seed); ENSURE(c->r_L, uint32_t, V, L);
+    rec_copy(c, r_vf, c->vf.p, (size_t)V * 48); rec_copy(c, r_owner, c->owner0.p, (size_t)V * 4); rec_copy(c, r_hc, c->hc.p, (size_t)(S0 + 1) * 48);
+    rec_copy(c, r_hcount, c->hcount.p, (size_t)(S0 + 1) * 4); rec_copy(c, r_gvox, c->ghost_vox.p, (size_t)(S0 + 1) * 4); rec_copy(c, r_gact, c->ghost_active.p, S0 + 1);
+    SweepBufs sb{&c->r_owner, &c->r_dist, &c->r_hc, &c->r_hcount, &c->r_hlo, &c->r_hhi, &c->r_gvox, &c->r_gact, &c->r_gdone, &c->r_ghead, &c->r_gnext,
+                 &c->r_tl, &c->r_tcnt, r_vf, seed, true};
+    int rc;
+    for (int it = 0; it < num_itr; ++it) {
+        rec_copy(c, L, r_owner, (size_t)V * 4);
+        rec<d_refine_ghost_L>(c, grid_for(S0, 256), 0u, S0, (const int*)r_gvox, (const unsigned char*)r_gact, L);
+        rec<d_refine_normals>(c, grid_for(V, 256), 0u, r_vf, (const int*)c->nbr.p, (const uint32_t*)r_owner, (const uint32_t*)L, V);
+        rec<d_reseed>(c, S0 ? S0 : 1u, 0u, (const float*)r_vf, V, S0, (const uint32_t*)r_hcount, (const float*)r_hc, seed);
+        if ((rc = seg_sweeps_on(c, sb)) || (rc = flush_sync(b))) return rc;
+        if (c->h_dc->error) return trace_err(c->h_dc->error, "refine", c);
+    }
+    if ((rc = flush_sync(b))) return rc;
+    c->refined_itr = num_itr;
+    return F3DS_OK;
+}
+
+// the refined state: per voxel (leaf order) its supervoxel label (0 = none) and normal
+extern "C" int f3ds_get_refined_voxels(f3ds_ctx* c, uint32_t* sv_label, float* normal, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame || c->refined_itr < 0) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
+    const uint32_t V = c->V;
+    if (n_out) *n_out = V;
+    if (!sv_label && !normal) return F3DS_OK;
+    if (cap < V) return F3DS_ERR_CAPACITY;
+    std::vector<float> f; std::vector<uint32_t> o;
+    int rc;
+    if ((rc = fetch(c, c->r_vf, (size_t)V * 12, f)) || (rc = fetch(c, c->r_owner, V, o))) return rc;
+    for (uint32_t v = 0; v < V; ++v) {
+        if (sv_label) sv_label[v] = o[v];
+        if (normal) { normal[3 * v] = f[(size_t)v * 12 + 6]; normal[3 * v + 1] = f[(size_t)v * 12 + 7]; normal[3 * v + 2] = f[(size_t)v * 12 + 8]; }
+    }
+    return F3DS_OK;
+}
+
+namespace {
+int supervoxels_of(f3ds_ctx* c, const Buf& hcount, const Buf& hcent, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels, size_t cap, size_t* n_out) {
     const uint32_t S0 = c->S0;
     std::vector<uint32_t> cnt; std::vector<float> hc;
     int rc;
-    if ((rc = fetch(c, c->hcount, S0 + 1, cnt)) || (rc = fetch(c, c->hc, (size_t)(S0 + 1) * 12, hc))) return rc;
+    if ((rc = fetch(c, hcount, S0 + 1, cnt)) || (rc = fetch(c, hcent, (size_t)(S0 + 1) * 12, hc))) return rc;
     size_t k = 0;
     for (uint32_t h = 1; h <= S0; ++h) {
         if (!cnt[h]) continue;
@@ -939,6 +1010,24 @@ extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, fl
     }
     if (n_out) *n_out = k;
     return (k > cap && (label || xyz || rgb || normal || n_voxels)) ? F3DS_ERR_CAPACITY : F3DS_OK;
+}
+}  // namespace
+
+// the refined supervoxel map (refined_supervoxel_clusters): same layout as f3ds_get_supervoxels
+extern "C" int f3ds_get_refined_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame || c->refined_itr < 0) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return supervoxels_of(c, c->r_hcount, c->r_hc, label, xyz, rgb, normal, n_voxels, cap, n_out);
+}
+
+extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    return supervoxels_of(c, c->hcount, c->hc, label, xyz, rgb, normal, n_voxels, cap, n_out);
 }
 
 extern "C" int f3ds_get_supervoxel_adjacency(f3ds_ctx* c, uint32_t* pairs, size_t cap_pairs, size_t* n_out) {

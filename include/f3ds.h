@@ -201,6 +201,19 @@ int f3ds_auto_threshold(f3ds_ctx* ctx, const f3ds_params* params, const uint32_t
                         size_t cap, size_t* n_out, float* best_threshold, f3ds_performance* best_score,
                         uint32_t* point_labels, int labels_on_device, f3ds_result* result);
 
+/* SupervoxelClustering::refineSupervoxels(num_itr, refined_supervoxel_clusters) (src/supervoxel_clustering.cpp:369-375) on
+ * the supervoxels of the last f3ds_segment call: num_itr times { normals again from the owned two-ring, reseed every
+ * supervoxel at the voxel nearest to its centroid, expand again }.  As in the reference, the refined supervoxels feed
+ * nothing downstream (the clustering keeps the unrefined ones, :424): they live beside the frame's state and are read
+ * with the two getters below; every other call keeps describing the unrefined supervoxels. */
+int f3ds_refine_supervoxels(f3ds_ctx* ctx, int num_itr);
+/* per voxel in leaf order (the order of f3ds_get_voxel_centroid_cloud): refined supervoxel label (0 = none) --
+ * getLabeledVoxelCloud / the per-voxel view of refined_full_labeled_cloud (:375) -- and refined normal (3 floats) */
+int f3ds_get_refined_voxels(f3ds_ctx* ctx, uint32_t* sv_label, float* normal, size_t cap, size_t* n_out);
+/* refined_supervoxel_clusters / makeSupervoxelNormalCloud(refined) (:373-374): layout of f3ds_get_supervoxels */
+int f3ds_get_refined_supervoxels(f3ds_ctx* ctx, uint32_t* label, float* xyz, float* rgb, float* normal, uint32_t* n_voxels,
+                                 size_t cap, size_t* n_out);
+
 /* ---- frame pipeline (row N4: the streaming surface the reference's ROS launch file points at,
  * launch/supervoxel_clustering.launch:3-6, README.md:72) ----------------------------------------
  * Frames go in from host memory one at a time and come out in submission order.  Up to `depth`

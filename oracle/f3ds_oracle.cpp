@@ -395,6 +395,7 @@ struct f3ds_oracle {
     std::vector<uint32_t> merges;            // M x 3
     std::vector<uint32_t> voxel_region;      // V
     std::vector<uint32_t> sv_region;         // S
+    std::list<Helper> helpers;               // supervoxel_helpers_ after extract (refineSupervoxels continues from them)
     std::map<uint32_t, SvPtr> initial_segments;
     std::multimap<uint32_t, uint32_t> adjacency;
     std::map<uint32_t, SvPtr> segments;      // final state
@@ -615,24 +616,14 @@ int select_seeds(f3ds_oracle& o) {
 }
 
 // ---- stage 3: createSupervoxelHelpers / expandSupervoxels / makeSupervoxels ------------------
-void expand_supervoxels(f3ds_oracle& o, std::list<Helper>& helpers) {
-    const f3ds_params& prm = o.prm;
-    for (size_t i = 0; i < o.seed_kept.size(); ++i) {
-        helpers.emplace_back();
-        Helper& h = helpers.back();
-        h.label = (uint32_t)(i + 1);
-        Voxel& leaf = o.vox[o.seed_kept[i]];
-        h.leaves.insert(leaf.idx);      // addLeaf
-        leaf.owner = &h;
-    }
-    int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
-    o.res.sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0;
+// expandSupervoxels(depth): depth-1 rounds of expand() on every helper, then erase the empty ones / updateCentroid
+void expand_loop(const f3ds_params& prm, std::vector<Voxel>& vox, std::list<Helper>& helpers, int max_depth) {
     for (int it = 1; it < max_depth; ++it) {
         for (Helper& h : helpers) {     // SupervoxelHelper::expand
             std::vector<int> new_owned;
             for (int li : h.leaves) {
-                for (int nb : o.vox[li].nbrs) {
-                    Voxel& nv = o.vox[nb];
+                for (int nb : vox[li].nbrs) {
+                    Voxel& nv = vox[nb];
                     if (nv.owner == &h) continue;
                     float dist = voxel_distance(prm, h.c, nv);
                     if (dist < nv.distance) {
@@ -654,7 +645,7 @@ void expand_supervoxels(f3ds_oracle& o, std::list<Helper>& helpers) {
                 for (int a = 0; a < 4; ++a) c.normal[a] = 0;
                 for (int a = 0; a < 3; ++a) { c.xyz[a] = 0; c.rgb[a] = 0; }
                 for (int li : hit->leaves) {
-                    const Voxel& v = o.vox[li];
+                    const Voxel& v = vox[li];
                     for (int a = 0; a < 4; ++a) c.normal[a] += v.normal[a];
                     for (int a = 0; a < 3; ++a) { c.xyz[a] += v.xyz[a]; c.rgb[a] += v.rgb[a]; }
                 }
@@ -664,6 +655,62 @@ void expand_supervoxels(f3ds_oracle& o, std::list<Helper>& helpers) {
                 ++hit;
             }
         }
+    }
+}
+void expand_supervoxels(f3ds_oracle& o, std::list<Helper>& helpers) {
+    const f3ds_params& prm = o.prm;
+    for (size_t i = 0; i < o.seed_kept.size(); ++i) {
+        helpers.emplace_back();
+        Helper& h = helpers.back();
+        h.label = (uint32_t)(i + 1);
+        Voxel& leaf = o.vox[o.seed_kept[i]];
+        h.leaves.insert(leaf.idx);      // addLeaf
+        leaf.owner = &h;
+    }
+    int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
+    o.res.sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0;
+    expand_loop(prm, o.vox, helpers, max_depth);
+}
+
+// SupervoxelClustering::refineSupervoxels(num_itr, ...) [PCL-recall], called at src/supervoxel_clustering.cpp:371:
+//   num_itr x { every helper: refineNormals(); reseedSupervoxels(); expandSupervoxels(max_depth) }, then makeSupervoxels.
+// Works on the voxels / helpers handed in (the caller passes copies: main() keeps clustering the unrefined supervoxels).
+void refine_supervoxels(const f3ds_params& prm, std::vector<Voxel>& vox, std::list<Helper>& helpers, int num_itr) {
+    const int max_depth = (int)(1.8f * prm.seed_res / prm.voxel_res);
+    std::vector<int> indices;
+    for (int it = 0; it < num_itr; ++it) {
+        // SupervoxelHelper::refineNormals: the two-ring list of computeVoxelData restricted to voxels this helper owns
+        // (the leaf itself is pushed unconditionally; a leaf held without being owned -- two seeds on one voxel -- gets
+        // its normal from every helper that holds it, the last one in list order stays)
+        for (Helper& h : helpers)
+            for (int li : h.leaves) {
+                Voxel& v = vox[li];
+                indices.clear();
+                indices.push_back(li);
+                for (int nb : v.nbrs) {
+                    if (vox[nb].owner != &h) continue;
+                    indices.push_back(nb);
+                    for (int nb2 : vox[nb].nbrs) if (vox[nb2].owner == &h) indices.push_back(nb2);
+                }
+                point_normal(indices.begin(), indices.end(), indices.size(), [&](int i) { return XYZ{vox[i].xyz[0], vox[i].xyz[1], vox[i].xyz[2]}; }, v.xyz, v.normal,
+                             &v.curvature);
+            }
+        // reseedSupervoxels: removeAllLeaves on every helper, then the voxel nearest to each helper's centroid
+        // (voxel_kdtree_->nearestKSearch(centroid, 1); fence F2: lowest index on exact ties) becomes its only leaf
+        for (Helper& h : helpers) {
+            for (int li : h.leaves) { vox[li].owner = nullptr; vox[li].distance = FLT_MAX; }
+            h.leaves.clear();
+        }
+        for (Helper& h : helpers) {
+            int best = -1; float bestd = 0;
+            for (int j = 0; j < (int)vox.size(); ++j) {
+                float r = 0.0f;
+                for (int k = 0; k < 3; ++k) { float d = h.c.xyz[k] - vox[j].xyz[k]; r += d * d; }      // flann::L2_Simple<float>
+                if (best < 0 || r < bestd) { best = j; bestd = r; }
+            }
+            if (best >= 0) { h.leaves.insert(best); vox[best].owner = &h; }      // addLeaf overwrites owner_
+        }
+        expand_loop(prm, vox, helpers, max_depth);
     }
 }
 
@@ -904,7 +951,7 @@ int f3ds_oracle_segment(const void* points16, size_t n, const f3ds_params* prm, 
     if (rc) return rc;
     o.res.n_seed_cells = (uint32_t)o.seed_orig.size();
     o.res.n_seeds = (uint32_t)o.seed_kept.size();
-    std::list<Helper> helpers;
+    std::list<Helper>& helpers = o.helpers;
     expand_supervoxels(o, helpers);
     // makeSupervoxels + getSupervoxelAdjacency
     for (Helper& h : helpers) {
@@ -931,7 +978,7 @@ int f3ds_oracle_segment(const void* points16, size_t n, const f3ds_params* prm, 
         for (uint32_t l : nl) o.adjacency.insert({h.label, l});
     }
     o.res.n_supervoxels = (uint32_t)helpers.size();
-    // keep per-voxel label/dist, then drop the Helper pointers (the list dies with this frame)
+    // keep per-voxel label/dist, then drop the Helper pointers (f3ds_oracle_refine rebuilds them on its copy)
     for (Voxel& v : o.vox) { v.svlabel = v.owner ? v.owner->label : 0; v.owner = nullptr; }
     rc = f3ds_oracle_cluster(&o, prm, labels, nullptr);
     if (rc) return rc;
@@ -1029,6 +1076,38 @@ int f3ds_oracle_get(f3ds_oracle* o, int what, void* dst, size_t cap, size_t* byt
 }
 
 void f3ds_oracle_free(f3ds_oracle* o) { delete o; }
+
+// refineSupervoxels(num_itr) on a copy of the extract state.  Outputs (any may be NULL): per voxel (leaf order) the
+// refined supervoxel label (0 = none) and normal (3 floats); per refined supervoxel in label order its label, 10 floats
+// (centroid xyz, rgb, normal4) and leaf count (leaves held, as makeSupervoxels copies them); n_sv_out = how many.
+int f3ds_oracle_refine(f3ds_oracle* op, int num_itr, uint32_t* voxel_sv_label, float* voxel_normal, uint32_t* sv_label, float* sv_feat, uint32_t* sv_count,
+                       size_t cap_sv, size_t* n_sv_out) {
+    if (!op || num_itr < 0) return F3DS_ERR_ARG;
+    std::vector<Voxel> vox = op->vox;
+    std::list<Helper> helpers = op->helpers;
+    std::map<uint32_t, Helper*> by_label;
+    for (Helper& h : helpers) by_label[h.label] = &h;
+    for (Voxel& v : vox) v.owner = v.svlabel ? by_label.at(v.svlabel) : nullptr;
+    refine_supervoxels(op->prm, vox, helpers, num_itr);
+    for (size_t i = 0; i < vox.size(); ++i) {
+        if (voxel_sv_label) voxel_sv_label[i] = vox[i].owner ? vox[i].owner->label : 0u;
+        if (voxel_normal) for (int a = 0; a < 3; ++a) voxel_normal[3 * i + a] = vox[i].normal[a];
+    }
+    size_t k = 0;
+    for (Helper& h : helpers) {
+        if (k < cap_sv) {
+            if (sv_label) sv_label[k] = h.label;
+            if (sv_feat) {
+                for (int a = 0; a < 3; ++a) { sv_feat[10 * k + a] = h.c.xyz[a]; sv_feat[10 * k + 3 + a] = h.c.rgb[a]; }
+                for (int a = 0; a < 4; ++a) sv_feat[10 * k + 6 + a] = h.c.normal[a];
+            }
+            if (sv_count) sv_count[k] = (uint32_t)h.leaves.size();
+        }
+        ++k;
+    }
+    if (n_sv_out) *n_sv_out = k;
+    return k > cap_sv && (sv_label || sv_feat || sv_count) ? F3DS_ERR_CAPACITY : F3DS_OK;
+}
 
 // known-answer-test entry points (tests/test_oracle.py)
 float f3ds_oracle_ciede00(const float* lab1, const float* lab2) { return lab_ciede00(lab1, lab2); }

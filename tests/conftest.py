@@ -92,6 +92,18 @@ class Handle:
         table = {float(ts[i]): ps[i].as_dict() for i in range(min(cnt.value, cap))}
         return rc, bt.value, bp, table, labels
 
+    def refine(self, num_itr):
+        V = len(self.get("VOXEL_SVLABEL")); S = len(self.get("SV_LABELS"))
+        vl = np.zeros(V, np.uint32); vn = np.zeros((V, 3), np.float32)
+        lab = np.zeros(S, np.uint32); feat = np.zeros((S, 10), np.float32); cnt = np.zeros(S, np.uint32); k = ctypes.c_size_t()
+        fn = self.chk.fn("refine")
+        fn.restype = ctypes.c_int
+        rc = fn(self.h, ctypes.c_int(num_itr), ctypes.c_void_p(vl.ctypes.data), ctypes.c_void_p(vn.ctypes.data), ctypes.c_void_p(lab.ctypes.data),
+                ctypes.c_void_p(feat.ctypes.data), ctypes.c_void_p(cnt.ctypes.data), ctypes.c_size_t(S), ctypes.byref(k))
+        assert rc == 0
+        k = k.value
+        return dict(voxel_label=vl, voxel_normal=vn, label=lab[:k], xyz=feat[:k, 0:3], rgb=feat[:k, 3:6], normal=feat[:k, 6:9], n_voxels=cnt[:k])
+
     def voxel_cloud(self):
         n = ctypes.c_size_t()
         self.chk.fn("voxel_cloud")(self.h, None, None, None, ctypes.c_size_t(0), ctypes.byref(n))

@@ -547,3 +547,40 @@ def test_frame_pipeline_buffers_capacity_and_threads(P, gpu_ctx):
             seen += 1
         th.join()
         assert fs.pending() == 0
+
+
+@pytest.mark.parametrize("name", ["rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags", "rgbd_320x240_large_supervoxels"])
+def test_refine_supervoxels_matches_oracle(P, oracle, gpu_ctx, name):
+    """Row N3: refineSupervoxels(k) -- owned-two-ring normals, reseeding at the voxel nearest to each centroid, sweeps
+    again -- bit for bit against the oracle's restatement, k = 0, 1 and the reference's 3 (src/supervoxel_clustering.cpp:371);
+    the frame's own supervoxels, labels and a later recluster do not notice."""
+    pts = case_points(P, name); prm = case_params(P, name)
+    rc, olab, ores, oh = oracle.segment(pts, prm)
+    glab = gpu_ctx.segment(pts, prm)
+    assert rc == 0 and np.array_equal(olab, glab)
+    with pytest.raises(P.F3dsError):
+        P._check(gpu_ctx.lib, gpu_ctx.lib.f3ds_get_refined_voxels(gpu_ctx.handle, None, None, 0, None))      # before refine: logic error
+    for k in (0, 1, 3):
+        want = oh.refine(k); got = gpu_ctx.refine_supervoxels(k)
+        for key in ("voxel_label", "label", "n_voxels", "voxel_normal", "xyz", "rgb", "normal"):
+            assert want[key].shape == got[key].shape, (k, key)
+            assert same_bits(want[key], got[key]), (k, key, first_mismatch(key, want[key], got[key]))
+    assert not first_mismatch("VOXEL_SVLABEL", oh.get("VOXEL_SVLABEL"), gpu_ctx.debug("VOXEL_SVLABEL"))
+    assert not first_mismatch("SV_CENTROID", oh.get("SV_CENTROID"), gpu_ctx.debug("SV_CENTROID"))
+    assert not first_mismatch("VOXEL_NORMAL", oh.get("VOXEL_NORMAL"), gpu_ctx.debug("VOXEL_NORMAL"))
+    assert np.array_equal(gpu_ctx.recluster(prm), olab)
+
+
+def test_refine_supervoxels_random_frames(P, oracle, gpu_ctx):
+    rng = np.random.default_rng(77)
+    for i in range(6):
+        w, h = int(rng.integers(40, 140)), int(rng.integers(30, 100))
+        pts = P.synth_frame(0, 9000 + i, w, h, int(rng.integers(0, 80)))
+        prm = P.launch_params(voxel_res=float(rng.choice([0.02, 0.03, 0.05])), seed_res=float(rng.choice([0.1, 0.2, 0.3])), use_transform=int(rng.integers(0, 2)))
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        glab = gpu_ctx.segment(pts, prm)
+        assert rc == 0 and np.array_equal(olab, glab)
+        k = int(rng.integers(1, 4))
+        want = oh.refine(k); got = gpu_ctx.refine_supervoxels(k)
+        for key in want:
+            assert want[key].shape == got[key].shape and same_bits(want[key], got[key]), (i, k, key)

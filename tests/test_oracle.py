@@ -155,3 +155,33 @@ def test_edge_cases(P, oracle, emul):
         assert ro[2].n_voxels == re[2].n_voxels and ro[2].n_regions == re[2].n_regions, name
     o = oracle.segment(cases["negative_z_folded"], prm)
     assert o[2].n_voxels == 1
+
+
+def test_refine_supervoxels_properties(P, oracle):
+    """refineSupervoxels restatement (row N3, [PCL-recall]): zero iterations hand back the extract state; after real
+    iterations the survivors are a subset of the supervoxels, every voxel they hold is counted once, none of them is
+    empty, owned normals are unit vectors, the result is a pure function of the extract state, and the oracle's main
+    state (supervoxels, clustering) is untouched."""
+    pts = case_points(P, "rgbd_160x120"); prm = case_params(P, "rgbd_160x120")
+    rc, lab, res, oh = oracle.segment(pts, prm)
+    assert rc == 0
+    sv0 = oh.get("VOXEL_SVLABEL").copy(); labels0 = oh.get("SV_LABELS").copy(); cent0 = oh.get("SV_CENTROID").reshape(-1, 10).copy()
+    r0 = oh.refine(0)
+    assert np.array_equal(r0["voxel_label"], sv0) and np.array_equal(r0["label"], labels0)
+    assert np.array_equal(r0["xyz"].view(np.uint32), cent0[:, 0:3].view(np.uint32)) and np.array_equal(r0["normal"].view(np.uint32), cent0[:, 6:9].view(np.uint32))
+    r3 = oh.refine(3)
+    assert set(r3["label"]) <= set(labels0) and len(r3["label"]) > 0.8 * len(labels0)
+    owned = r3["voxel_label"] != 0
+    counts = np.bincount(r3["voxel_label"][owned], minlength=int(labels0.max()) + 1)
+    for l, n in zip(r3["label"], r3["n_voxels"]):
+        assert n >= counts[l] >= 1 and n - counts[l] <= 1          # a leaf held without being owned adds at most one
+    assert counts.sum() == owned.sum() and set(np.nonzero(counts)[0]) == set(r3["label"])
+    nn = np.linalg.norm(r3["voxel_normal"][owned], axis=1)
+    assert np.all((np.abs(nn - 1) < 1e-5) | (nn == 0))
+    assert (r3["voxel_label"] != sv0).any()                         # it did move boundaries
+    r3b = oh.refine(3)
+    for k in r3:
+        assert np.array_equal(r3[k].view(np.uint32), r3b[k].view(np.uint32)), k      # a pure function of the extract state
+    assert np.array_equal(oh.get("VOXEL_SVLABEL"), sv0) and np.array_equal(oh.get("SV_CENTROID").reshape(-1, 10).view(np.uint32), cent0.view(np.uint32))
+    rc2, lab2, _ = oh.cluster(prm, len(pts))
+    assert rc2 == 0 and np.array_equal(lab2, lab)
