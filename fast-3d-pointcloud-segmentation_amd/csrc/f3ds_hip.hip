@@ -598,7 +598,7 @@ int finish_empty(f3ds_ctx* c, hipStream_t st, uint32_t* point_labels, int labels
     ENSURE(c->labels, uint32_t, c->n ? c->n : 1, d_labels);
     if (c->n) {
         HIPCHECK(hipMemsetAsync(d_labels, 0xFF, (size_t)c->n * 4, st));
-        if (point_labels) HIPCHECK(hipMemcpyAsync(point_labels, d_labels, (size_t)c->n * 4, labels_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        if (point_labels) HIPCHECK(hipMemcpyAsync(point_labels, d_labels, (size_t)c->n * 4, labels_on_device ? hipMemcpyDefault : hipMemcpyDeviceToHost, st));
     }
     c->have_frame = false; c->live = false;
     return F3DS_OK;

@@ -22,6 +22,11 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
     except Exception as ex:
         rc2 = getattr(ex, "code", -99); elab = None
     ok = rc == rc2 and (rc != 0 or (np.array_equal(olab, elab) and all(conftest.same_bits(oh.get(k), ctx.debug(k)) for k in conftest.ALL_DEBUG)))
+    if ok and rc == 0:                                   # row N3 on the same frame
+        k = int(rng.integers(1, 4))
+        want = oh.refine(k); got = ctx.refine_supervoxels(k)
+        ok = all(want[key].shape == got[key].shape and conftest.same_bits(want[key], got[key]) for key in want)
+        if not ok: print("  refine(%d) differs" % k)
     print(it, "ok" if ok else "MISMATCH", rc, rc2, w, hgt, kind, seed, kw, "V", ores.n_voxels, "S", ores.n_seeds, "merges", ores.n_merges, flush=True)
     bad += not ok
 print("bad", bad)
