@@ -154,10 +154,26 @@ int ensure(Buf& b, size_t count, T** out) {
 }
 #define ENSURE(buf, T, count, ptr) do { int rc_ = ensure<T>(buf, (size_t)(count), &ptr); if (rc_) return rc_; } while (0)
 
+// Workgroups per frame of a wide kernel.  A launch covers all frames of the batch (grid.y = frame), so a frame gets its
+// share of a launch-wide budget of ~6 k workgroups (24 per CU) and the kernels loop (grid-stride) over the rest: with
+// 192 frames per launch the streaming kernels of the sweeps run 1.5-2x faster on 32 fat workgroups per frame than on
+// 300 thin ones (per-workgroup prologue: argument pack, counters, stamps), see DESIGN.md 4b.  The hash-probing /
+// gathering kernels want every wave they can get and keep the old cap (grid_wide).  Set per batch call (one host thread).
+thread_local size_t g_grid_cap = 2048;
+size_t grid_cap_for_batch(int frames) {
+    static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 6144;
+    if (!target) return 2048;
+    size_t cap = target / (size_t)(frames > 0 ? frames : 1);
+    return cap < 8 ? 8 : (cap > 2048 ? 2048 : cap);
+}
+inline uint32_t grid_wide(size_t work, int block) {
+    size_t g = (work + block - 1) / block;
+    return (uint32_t)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
 inline uint32_t grid_for(size_t work, int block) {
     size_t g = (work + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;          // grid-stride beyond 256 CUs x 8 workgroups
+    if (g > g_grid_cap) g = g_grid_cap;
     return (uint32_t)g;
 }
 inline uint32_t pow2_ge(size_t x) { uint32_t p = 1; while (p < x) p <<= 1; return p; }
@@ -338,10 +354,10 @@ int seg_voxels(f3ds_ctx* c) {
     ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hcap, hkeys); ENSURE(c->hvals, uint32_t, hcap, hvals);
     P16* spts; ENSURE(c->spts, P16, n, spts);
     rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hcap * 8);
-    rec<d_point_gather>(c, grid_for(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
-    rec<d_voxel_accum>(c, grid_for(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
+    rec<d_point_gather>(c, grid_wide(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
+    rec<d_voxel_accum>(c, grid_wide(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
                        (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask);
-    rec<d_neighbors>(c, grid_for((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
+    rec<d_neighbors>(c, grid_wide((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                      c->hmask, nbr, nbrT);
     rec<d_normals>(c, (V + NT_TILE - 1) / NT_TILE, 0u, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
     const uint32_t nchunks = (V + SEED_CHUNK - 1) / SEED_CHUNK;
@@ -751,6 +767,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     HIPCHECK(hipSetDevice(ctxs[0]->device));
     Batch b;
     b.owner = ctxs[0]; b.st = ctxs[0]->stream;
+    g_grid_cap = grid_cap_for_batch(nctx);
     std::vector<int> index_of;
     const int max_depth = (int)(1.8f * prm->seed_res / prm->voxel_res);      // [PCL-recall] SupervoxelClustering::extract
     const uint32_t sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0u;
@@ -849,7 +866,7 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHECK(hipSetDevice(c->device));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
     c->cmds.clear(); c->blob.clear();
     c->h_dc->error = 0;
     HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), c->stream));
@@ -943,7 +960,7 @@ extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
     if (!c || num_itr < 0) return F3DS_ERR_ARG;
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     HIPCHECK(hipSetDevice(c->device));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
     c->cmds.clear(); c->blob.clear();
     c->refined_itr = -1;
     const uint32_t V = c->V, S0 = c->S0;
@@ -1130,7 +1147,7 @@ int eval_truth(f3ds_ctx* c, const uint32_t* truth_point_labels) {
     HIPCHECK(hipMemcpyAsync(lut, f3ds_glasbey_256, 1024, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(tp, truth_point_labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemsetAsync(tsum, 0, (size_t)V * 12, c->stream));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
     c->cmds.clear(); c->blob.clear();
     rec<d_truth_accum>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)tp, (const uint32_t*)lut, tsum);
     rec<d_truth_color>(c, grid_for(V, 256), 0u, V, (const uint32_t*)tsum, (const uint32_t*)c->vcount.p, tcol);
@@ -1158,7 +1175,7 @@ int eval_scores(f3ds_ctx* c, const uint32_t* d_root, const uint32_t* d_incl, uin
     ENSURE(c->ctab, uint32_t, (size_t)K * M, tab); ENSURE(c->csize, uint32_t, K, ssz);
     HIPCHECK(hipMemsetAsync(tab, 0, (size_t)K * M * 4, c->stream));
     HIPCHECK(hipMemsetAsync(ssz, 0, (size_t)K * 4, c->stream));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
     c->cmds.clear(); c->blob.clear();
     rec<d_contingency>(c, grid_for(V, 256), 0u, V, M, (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
     rec<d_contingency_ghost>(c, grid_for(c->S0, 256), 0u, c->S0, M, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p,

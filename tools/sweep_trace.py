@@ -10,10 +10,10 @@ for r in csv.DictReader(open(f)):
     if not m or r["Grid_Size_Y"] != nf:
         continue
     seq[m.group(0)].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-for n in ("d_sweep_begin", "d_sweep_R_round", "d_sweep_R", "d_sweep_claim", "d_centroid"):
+for n in ("d_sweep_begin", "d_sweep_R_round", "d_sweep_R_pre", "d_sweep_R", "d_sweep_R_tail", "d_sweep_claim", "d_claim_mark", "d_centroid", "d_centroid_mark"):
     v = sorted(seq.get(n, []))
     if not v:
         continue
-    per = 64 if n == "d_sweep_R_round" else 16
+    per = 48 if n == "d_sweep_R_round" else 16
     last = [round(x[1]) for x in v[-per:]]
     print("%-16s sum %6d us  %s" % (n, sum(last), last))
