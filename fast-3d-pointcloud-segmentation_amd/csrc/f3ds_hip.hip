@@ -455,8 +455,8 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
         rec<d_sweep_R_tail>(c, 1u, 0u, a, a_sweep_tag(t), t);
         rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
         if (g_inc_shift >= 0) rec<d_claim_mark>(c, grid_for(V, 256), 0u, a, t);
-        rec<d_centroid>(c, (S0 + 3u) / 4u + (S0 ? 0u : 1u), 0u, a, t);
-        if (g_inc_shift >= 0) rec<d_centroid_mark>(c, (S0 + 3u) / 4u + (S0 ? 0u : 1u), 0u, a, t);
+        rec<d_centroid>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
+        if (g_inc_shift >= 0) rec<d_centroid_mark>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
     }
     return F3DS_OK;
 }
