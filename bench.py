@@ -151,6 +151,9 @@ def main():
 
     run_steps(args.warmup, False)
     barrier()
+    if os.environ.get("F3DS_BENCH_MEMINFO"):                      # development: HBM in use after warm-up (contexts are grow-only)
+        free, total = torch.cuda.mem_get_info(dev)
+        print("rank %d: %.1f GB of %.1f GB HBM in use" % (rank, (total - free) / 2**30, total / 2**30), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     barrier()
