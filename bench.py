@@ -126,6 +126,7 @@ def main():
                     if world > 1:   # label output of this batch: one RCCL gather of the whole label block to rank 0
                         with stage_lock:
                             B.gather_label_block(label_blocks[g], dist, gather_list, dst=0)
+                            torch.cuda.current_stream().synchronize()      # the block is reused by this group's next batch (on libf3ds' own stream)
                     if record:      # ms_stage is the device time of each stage of the whole batch (HIP events on the batch stream)
                         with stage_lock:
                             for j in range(7):
