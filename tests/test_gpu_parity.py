@@ -484,6 +484,18 @@ def test_frame_pipeline_returns_every_frame_in_order_with_the_labels_of_single_c
         assert (res.n_points, res.n_voxels, res.n_regions) == (len(frames[i]), want[i][1], want[i][2]), i
 
 
+def test_frame_pipeline_run_generator(P, gpu_ctx):
+    """FrameStream.run: an iterable of frames in, (index, labels, Result) out in order, with more frames than slots."""
+    prm = P.launch_params(voxel_res=0.02, seed_res=0.2)
+    frames = [P.synth_frame(0, 6000 + i, 80 + 8 * (i % 4), 60, 10) for i in range(9)]
+    want = [gpu_ctx.segment(f, prm) for f in frames]
+    with P.FrameStream(0, depth=3) as fs:
+        got = list(fs.run(iter(frames), prm))
+    assert [g[0] for g in got] == list(range(9))
+    for i, (_, lab, res) in enumerate(got):
+        assert np.array_equal(lab, want[i]) and res.n_points == len(frames[i]), i
+
+
 def test_frame_pipeline_buffers_capacity_and_threads(P, gpu_ctx):
     """Zero-copy submission through the slot's pinned buffer, F3DS_ERR_CAPACITY leaves the frame in place, a frame that
     fails (voxel grid too deep) reports its own status without disturbing its neighbours, and a producer thread
