@@ -26,6 +26,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 #include "../../include/f3ds.h"
@@ -620,6 +621,24 @@ int finish_empty(f3ds_ctx* c, hipStream_t st, uint32_t* point_labels, int labels
     return F3DS_OK;
 }
 
+// Streams for batch calls.  HIP multiplexes streams onto a few hardware queues (4 by default) in creation order, and two
+// batches whose streams share a hardware queue run one after the other (measured: with 576 contexts created in a row, two
+// of bench.py's three concurrent batches landed in one queue).  A batch therefore does not run on its first context's
+// stream but on one of four streams per device created back to back -- four different queues -- and held for the call.
+struct BatchStreamPool { std::mutex m; hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; bool busy[4] = {false, false, false, false}; };
+BatchStreamPool g_batch_streams[16];
+struct BatchStreamLease {
+    int dev = -1, slot = -1;
+    hipStream_t acquire(int device) {
+        BatchStreamPool& p = g_batch_streams[device & 15];
+        std::lock_guard<std::mutex> lk(p.m);
+        if (!p.s[0]) for (auto& st : p.s) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return nullptr; }
+        for (int i = 0; i < 4; ++i) if (!p.busy[i] && p.s[i]) { p.busy[i] = true; dev = device & 15; slot = i; return p.s[i]; }
+        return nullptr;      // more than four batches at once on this device: the caller's own stream
+    }
+    ~BatchStreamLease() { if (slot >= 0) { std::lock_guard<std::mutex> lk(g_batch_streams[dev].m); g_batch_streams[dev].busy[slot] = false; } }
+};
+
 // run `fn` (a per-frame recorder) on every live frame; a failing frame fails the batch
 template <class F>
 int for_frames(Batch& b, F&& fn) {
@@ -767,6 +786,8 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     HIPCHECK(hipSetDevice(ctxs[0]->device));
     Batch b;
     b.owner = ctxs[0]; b.st = ctxs[0]->stream;
+    BatchStreamLease lease;
+    if (nctx > 1 && ctxs[0]->stream == ctxs[0]->own_stream && !getenv("F3DS_NO_STREAM_POOL")) { hipStream_t ps = lease.acquire(ctxs[0]->device); if (ps) b.st = ps; }
     g_grid_cap = grid_cap_for_batch(nctx);
     std::vector<int> index_of;
     const int max_depth = (int)(1.8f * prm->seed_res / prm->voxel_res);      // [PCL-recall] SupervoxelClustering::extract
