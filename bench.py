@@ -53,10 +53,10 @@ HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2304)
-    ap.add_argument("--warmup", type=int, default=576)
+    ap.add_argument("--steps", type=int, default=3072)
+    ap.add_argument("--warmup", type=int, default=768)
     ap.add_argument("--batch", type=int, default=192, help="frames per f3ds_segment_batch call")
-    ap.add_argument("--groups", type=int, default=3, help="batch calls in flight per GPU")
+    ap.add_argument("--groups", type=int, default=4, help="batch calls in flight per GPU (libf3ds runs up to four on distinct hardware queues)")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames to cycle through")
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--height", type=int, default=1000)
