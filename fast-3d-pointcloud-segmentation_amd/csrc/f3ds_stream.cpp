@@ -105,7 +105,7 @@ int f3ds_stream_create(int device, int depth, int groups, f3ds_stream** out) {
     if (!out) return F3DS_ERR_ARG;
     *out = nullptr;
     if (depth <= 0 || depth > 4096 || groups < 0) return F3DS_ERR_ARG;
-    if (groups == 0) groups = depth < 3 ? depth : 3;
+    if (groups == 0) groups = depth < 4 ? depth : 4;      // libf3ds runs up to four batch calls on distinct hardware queues
     if (groups > depth) groups = depth;
     f3ds_stream* s = new f3ds_stream;
     s->device = device; s->depth = depth; s->max_batch = (depth + groups - 1) / groups;
