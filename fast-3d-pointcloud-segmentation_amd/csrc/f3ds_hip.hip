@@ -624,17 +624,19 @@ int finish_empty(f3ds_ctx* c, hipStream_t st, uint32_t* point_labels, int labels
 // Streams for batch calls.  HIP multiplexes streams onto a few hardware queues (4 by default) in creation order, and two
 // batches whose streams share a hardware queue run one after the other (measured: with 576 contexts created in a row, two
 // of bench.py's three concurrent batches landed in one queue).  A batch therefore does not run on its first context's
-// stream but on one of four streams per device created back to back -- four different queues -- and held for the call.
-struct BatchStreamPool { std::mutex m; hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; bool busy[4] = {false, false, false, false}; };
+// stream but on one of four streams per device (GPU_MAX_HW_QUEUES of them if that is set) created back to back --
+// different queues -- and held for the call.
+struct BatchStreamPool { std::mutex m; hipStream_t s[8] = {}; bool busy[8] = {}; };
+const int g_batch_stream_count = [] { const char* e = getenv("GPU_MAX_HW_QUEUES"); int n = e ? atoi(e) : 4; return n < 1 ? 1 : (n > 8 ? 8 : n); }();      // one per hardware queue HIP will use
 BatchStreamPool g_batch_streams[16];
 struct BatchStreamLease {
     int dev = -1, slot = -1;
     hipStream_t acquire(int device) {
         BatchStreamPool& p = g_batch_streams[device & 15];
         std::lock_guard<std::mutex> lk(p.m);
-        if (!p.s[0]) for (auto& st : p.s) if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return nullptr; }
-        for (int i = 0; i < 4; ++i) if (!p.busy[i] && p.s[i]) { p.busy[i] = true; dev = device & 15; slot = i; return p.s[i]; }
-        return nullptr;      // more than four batches at once on this device: the caller's own stream
+        if (!p.s[0]) for (int i = 0; i < g_batch_stream_count; ++i) if (hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) != hipSuccess) { p.s[i] = nullptr; return nullptr; }
+        for (int i = 0; i < g_batch_stream_count; ++i) if (!p.busy[i] && p.s[i]) { p.busy[i] = true; dev = device & 15; slot = i; return p.s[i]; }
+        return nullptr;      // more batches at once on this device than queues: the caller's own stream
     }
     ~BatchStreamLease() { if (slot >= 0) { std::lock_guard<std::mutex> lk(g_batch_streams[dev].m); g_batch_streams[dev].busy[slot] = false; } }
 };
