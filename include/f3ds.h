@@ -121,9 +121,11 @@ int f3ds_segment(f3ds_ctx* ctx, const void* points, size_t n, int points_on_devi
                  f3ds_result* result);
 
 /* A batch of independent frames on one GPU, one context per frame (BASELINE.json config 5 puts 8
- * frames on each GPU).  Same result per frame as f3ds_segment; the frames' wide stages run
- * concurrently on their contexts' streams and all merge loops run as one dispatch.  points[i] /
- * point_labels[i] / counts[i] belong to ctxs[i]; results may be NULL.  Synchronous. */
+ * frames on each GPU).  Same result per frame as f3ds_segment; every kernel of the path is one
+ * dispatch for all frames and all merge loops run as one dispatch.  points[i] / point_labels[i] /
+ * counts[i] belong to ctxs[i]; results may be NULL.  Synchronous.  The batch runs on the stream set
+ * with f3ds_set_stream on ctxs[0] if there is one, else on one of a few library-owned streams per
+ * device (one per hardware queue), so that batch calls from several host threads run side by side. */
 int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, const size_t* counts,
                        int points_on_device, const f3ds_params* params, uint32_t* const* point_labels,
                        int labels_on_device, f3ds_result* results);
