@@ -496,6 +496,23 @@ def test_frame_pipeline_run_generator(P, gpu_ctx):
         assert np.array_equal(lab, want[i]) and res.n_points == len(frames[i]), i
 
 
+def test_frame_pipeline_can_be_destroyed_with_frames_in_flight(P, gpu_ctx):
+    """f3ds_stream_destroy lets the workers finish the batch they are in and drops what was never taken; a new pipeline
+    (and the plain context) work afterwards."""
+    prm = P.launch_params(voxel_res=0.02, seed_res=0.2)
+    f0 = P.synth_frame(0, 7000, 160, 120, 10)
+    w0 = gpu_ctx.segment(f0, prm)
+    fs = P.FrameStream(0, depth=6, groups=2)
+    for i in range(6):
+        assert fs.submit(f0, prm, i)
+    fs.close()                                                   # nothing taken
+    fs.close()                                                   # idempotent
+    with P.FrameStream(0, depth=2) as fs2:
+        assert fs2.submit(f0, prm, 1)
+        assert np.array_equal(fs2.next()[1], w0)
+    assert np.array_equal(gpu_ctx.segment(f0, prm), w0)
+
+
 def test_frame_pipeline_buffers_capacity_and_threads(P, gpu_ctx):
     """Zero-copy submission through the slot's pinned buffer, F3DS_ERR_CAPACITY leaves the frame in place, a frame that
     fails (voxel grid too deep) reports its own status without disturbing its neighbours, and a producer thread
