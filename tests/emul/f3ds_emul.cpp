@@ -220,15 +220,19 @@ int stage_seeds(f3ds_emul& E) {
     return 0;
 }
 
-int stage_sweeps(f3ds_emul& E) {
+// seeds: one voxel per helper label 1..S0 (-1: a helper erased earlier, refineSupervoxels only); reseed: the centroids
+// stay what the last updateCentroid left (d_reseed_own / d_reseed_init on the device) instead of zeros
+int stage_sweeps(f3ds_emul& E, const std::vector<int>& seeds, bool reseed) {
     const f3ds_params& prm = E.prm;
     const int V = E.V;
-    const int S0 = (int)E.seed_kept.size();
+    const int S0 = (int)seeds.size();
     E.owner.assign(V, 0u); E.dist.assign(V, F3DS_FLT_MAX);
-    E.hc.assign((size_t)(S0 + 1) * 12, 0.0f); E.hcount.assign(S0 + 1, 0u);
+    if (!reseed) E.hc.assign((size_t)(S0 + 1) * 12, 0.0f);
+    E.hcount.assign(S0 + 1, 0u);
     E.ghost_vox.assign(S0 + 1, -1); E.ghost_active.assign(S0 + 1, 0);
-    for (int i = 0; i < S0; ++i) {          // createSupervoxelHelpers: addLeaf overwrites owner_
-        int v = E.seed_kept[i];
+    for (int i = 0; i < S0; ++i) {          // createSupervoxelHelpers / reseedSupervoxels: addLeaf overwrites owner_
+        int v = seeds[i];
+        if (v < 0) continue;
         if (E.owner[v] != 0u) { E.ghost_vox[E.owner[v]] = v; E.ghost_active[E.owner[v]] = 1; }
         E.owner[v] = (uint32_t)(i + 1);
         E.hcount[i + 1] = 1;
@@ -586,7 +590,7 @@ int f3ds_emul_segment(const void* points16, size_t n, const f3ds_params* prm, ui
     rc = stage_seeds(E);
     if (rc) return rc;
     E.res.n_seed_cells = (uint32_t)E.seed_orig.size(); E.res.n_seeds = (uint32_t)E.seed_kept.size();
-    rc = stage_sweeps(E);
+    rc = stage_sweeps(E, E.seed_kept, false);
     if (rc) return rc;
     rc = f3ds_emul_cluster(&E, prm, labels, nullptr);
     if (rc) return rc;
@@ -653,6 +657,78 @@ int f3ds_emul_get(f3ds_emul* E, int what, void* dst, size_t cap, size_t* bytes_o
 }
 
 void f3ds_emul_free(f3ds_emul* E) { delete E; }
+
+// refineSupervoxels the way the device does it (f3ds_refine_supervoxels in csrc/f3ds_hip.hip): on copies of the sweep state,
+// num_itr x { normals from the owned two-ring (the helper that writes a voxel last: its owner or a higher ghost holder),
+// exact nearest voxel to every live helper's centroid, the sweeps again with the centroids kept }.  Same outputs as
+// f3ds_oracle_refine.
+int f3ds_emul_refine(f3ds_emul* Ep, int num_itr, uint32_t* voxel_sv_label, float* voxel_normal, uint32_t* sv_label, float* sv_feat, uint32_t* sv_count,
+                     size_t cap_sv, size_t* n_sv_out) {
+    if (!Ep || num_itr < 0) return F3DS_ERR_ARG;
+    f3ds_emul& E = *Ep;
+    const int V = E.V, S0 = (int)E.seed_kept.size();
+    // the frame's own state comes back at the end
+    const std::vector<float> vf0 = E.vf, dist0 = E.dist, hc0 = E.hc;
+    const std::vector<uint32_t> owner0 = E.owner, hcount0 = E.hcount;
+    const std::vector<int> gv0 = E.ghost_vox; const std::vector<uint8_t> ga0 = E.ghost_active;
+    const f3ds_result res0 = E.res;
+    for (int it = 0; it < num_itr; ++it) {
+        std::vector<uint32_t> L = E.owner;                                   // d_refine_ghost_L
+        for (int h = 1; h <= S0; ++h) if (E.ghost_active[h] && E.ghost_vox[h] >= 0 && (uint32_t)h > L[E.ghost_vox[h]]) L[E.ghost_vox[h]] = (uint32_t)h;
+        for (int v = 0; v < V; ++v) {                                        // d_refine_normals (reads xyz only, writes normals)
+            const uint32_t me = L[v];
+            if (!me) continue;
+            float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned cnt = 0;
+            auto add = [&](int u) {
+                const float* q = &E.vf[(size_t)u * 12];
+                acc[0] += q[0] * q[0]; acc[1] += q[0] * q[1]; acc[2] += q[0] * q[2];
+                acc[3] += q[1] * q[1]; acc[4] += q[1] * q[2]; acc[5] += q[2] * q[2];
+                acc[6] += q[0]; acc[7] += q[1]; acc[8] += q[2];
+                cnt++;
+            };
+            add(v);
+            for (int s1 = 0; s1 < 27; ++s1) {
+                const int u = E.nbr[(size_t)v * 27 + s1];
+                if (u < 0 || E.owner[u] != me) continue;
+                add(u);
+                for (int s2 = 0; s2 < 27; ++s2) { const int u2 = E.nbr[(size_t)u * 27 + s2]; if (u2 >= 0 && E.owner[u2] == me) add(u2); }
+            }
+            float n4[4];
+            n_plane_normal(acc, cnt, &E.vf[(size_t)v * 12], n4);
+            E.vf[(size_t)v * 12 + 6] = n4[0]; E.vf[(size_t)v * 12 + 7] = n4[1]; E.vf[(size_t)v * 12 + 8] = n4[2];
+        }
+        std::vector<int> seeds(S0, -1);                                      // d_reseed
+        for (int h = 1; h <= S0; ++h) {
+            if (!E.hcount[h]) continue;
+            int best = -1; float bd = 0.0f;
+            for (int v = 0; v < V; ++v) {
+                const float d = a_sqdist(&E.hc[(size_t)h * 12], &E.vf[(size_t)v * 12]);
+                if (best < 0 || d < bd) { best = v; bd = d; }
+            }
+            seeds[h - 1] = best;
+        }
+        int rc = stage_sweeps(E, seeds, true);
+        if (rc) return rc;
+    }
+    for (int v = 0; v < V; ++v) {
+        if (voxel_sv_label) voxel_sv_label[v] = E.owner[v];
+        if (voxel_normal) for (int a = 0; a < 3; ++a) voxel_normal[3 * v + a] = E.vf[(size_t)v * 12 + 6 + a];
+    }
+    size_t k = 0;
+    for (int h = 1; h <= S0; ++h) {
+        if (!E.hcount[h]) continue;
+        if (k < cap_sv) {
+            if (sv_label) sv_label[k] = (uint32_t)h;
+            if (sv_feat) { for (int a = 0; a < 9; ++a) sv_feat[10 * k + a] = E.hc[(size_t)h * 12 + a]; sv_feat[10 * k + 9] = 0.0f; }
+            if (sv_count) sv_count[k] = E.hcount[h];
+        }
+        ++k;
+    }
+    if (n_sv_out) *n_sv_out = k;
+    E.vf = vf0; E.dist = dist0; E.hc = hc0; E.owner = owner0; E.hcount = hcount0; E.ghost_vox = gv0; E.ghost_active = ga0; E.res = res0;
+    return k > cap_sv && (sv_label || sv_feat || sv_count) ? F3DS_ERR_CAPACITY : F3DS_OK;
+}
 
 // numerics probes for tests/test_numerics.py (device arithmetic evaluated on the host)
 float f3ds_emul_ciede00(const float* l1, const float* l2) { return n_ciede00(l1, l2); }

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALL_DEBUG, FIXTURE_PCD, ROOT
+from conftest import same_bits, ALL_DEBUG, FIXTURE_PCD, ROOT
 from golden_cases import GOLDEN_CASES, case_params, case_points
 
 KAT = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))
@@ -185,3 +185,39 @@ def test_refine_supervoxels_properties(P, oracle):
     assert np.array_equal(oh.get("VOXEL_SVLABEL"), sv0) and np.array_equal(oh.get("SV_CENTROID").reshape(-1, 10).view(np.uint32), cent0.view(np.uint32))
     rc2, lab2, _ = oh.cluster(prm, len(pts))
     assert rc2 == 0 and np.array_equal(lab2, lab)
+
+
+@pytest.mark.parametrize("name", ["rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags"])
+def test_refine_device_formulation_matches_oracle_on_cpu(P, oracle, emul, name):
+    """Row N3 without a GPU: the device's way of refining (tests/emul: last-writer rule for the normals of ghost leaves,
+    brute-force reseed, the R-predicate sweeps with kept centroids and seedless helpers) against the literal restatement."""
+    pts = case_points(P, name); prm = case_params(P, name)
+    rc, olab, ores, oh = oracle.segment(pts, prm)
+    rc2, elab, eres, eh = emul.segment(pts, prm)
+    assert rc == 0 and rc2 == 0 and np.array_equal(olab, elab)
+    sv0 = eh.get("VOXEL_SVLABEL").copy()
+    for k in (1, 3):
+        want = oh.refine(k); got = eh.refine(k)
+        for key in want:
+            assert want[key].shape == got[key].shape and same_bits(want[key], got[key]), (k, key)
+    assert np.array_equal(eh.get("VOXEL_SVLABEL"), sv0)
+    rc3, lab3, _ = eh.cluster(prm, len(pts))
+    assert rc3 == 0 and np.array_equal(lab3, olab)
+
+
+def test_refine_device_formulation_random_frames_cpu(P, oracle, emul):
+    rng = np.random.default_rng(2024)
+    for i in range(10):
+        w, h = int(rng.integers(30, 110)), int(rng.integers(24, 80))
+        pts = P.synth_frame(0, 8100 + i, w, h, int(rng.integers(0, 100)))
+        vres = float(rng.choice([0.02, 0.03, 0.05]))
+        prm = P.launch_params(voxel_res=vres, seed_res=vres * float(rng.choice([2, 3, 5, 10])), use_transform=int(rng.integers(0, 2)), leaf_order=int(rng.integers(0, 2)))
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        rc2, elab, eres, eh = emul.segment(pts, prm)
+        assert rc == rc2
+        if rc:
+            continue
+        k = int(rng.integers(1, 4))
+        want = oh.refine(k); got = eh.refine(k)
+        for key in want:
+            assert want[key].shape == got[key].shape and same_bits(want[key], got[key]), (i, k, key)
