@@ -70,7 +70,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # development: F3DS_BENCH_FORCE_DIST=1 takes the RCCL path (process group, label gather, barrier) with one rank too
+    dist_on = world > 1 or bool(os.environ.get("F3DS_BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -99,7 +101,7 @@ def main():
     # one contiguous label block per group: the batch's label output is ONE RCCL gather (nbatch x 4 MB per rank)
     label_blocks = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(ngroups)]
     label_bufs = [[label_blocks[g][i] for i in range(nbatch)] for g in range(ngroups)]
-    gather_list = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_list = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None
     torch.cuda.synchronize()
 
     stage_ms = [0.0] * 7
@@ -123,7 +125,7 @@ def main():
                     k = len(steps)
                     P.segment_batch(ctxs[g][:k], [frames_dev[s % len(frames_dev)].data_ptr() for s in steps], prm,
                                     labels_out=[label_bufs[g][i].data_ptr() for i in range(k)], n=[npts] * k, on_device=True)
-                    if world > 1:   # label output of this batch: one RCCL gather of the whole label block to rank 0
+                    if dist_on:     # label output of this batch: one RCCL gather of the whole label block to rank 0
                         with stage_lock:
                             B.gather_label_block(label_blocks[g], dist, gather_list, dst=0)
                             torch.cuda.current_stream().synchronize()      # the block is reused by this group's next batch (on libf3ds' own stream)
@@ -146,7 +148,7 @@ def main():
             raise errors[0]
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +165,7 @@ def main():
     run_steps(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -218,14 +220,14 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t %g" % (args.width, args.height, npts, prm.threshold),
                            "frames_in_flight_per_gpu": nstreams, "setup": "one untimed pass over all contexts (scratch allocation) before the warm-up steps", "batch": nbatch, "concurrent_batches": ngroups, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
-                           "label_gather": "one RCCL gather of the batch's label block (batch x 4 MB per rank) to rank 0 per batch" if world > 1 else "none",
+                           "label_gather": "one RCCL gather of the batch's label block (batch x 4 MB per rank) to rank 0 per batch" if dist_on else "none",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
                 "single_stream_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     for grp in ctxs:
         for c in grp:
             c.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
