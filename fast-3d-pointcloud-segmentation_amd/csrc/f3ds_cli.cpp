@@ -4,7 +4,7 @@
 //
 // Kept from the reference: -d/-p, -v -s -c -z -n, -t, --RGB --CVX --ML --AL --EQ, -r, -f, --NT, --V.
 // Added (additive): -o <pcd> coloured voxel cloud (Clustering::get_colored_cloud), --labels <file>
-// per-point uint32 region ids, --gpu <id>, --stream <depth> (label files only: the files go through the frame
+// per-point uint32 region ids, --gpu <id>, --refine <n> (refineSupervoxels, :369-375), --stream <depth> (label files only: the files go through the frame
 // pipeline f3ds_stream_*, reading ahead of the GPU, no evaluation).  Without -t the threshold is chosen by the ground-truth sweep
 // (all_thresh 0.8..1 step 0.005 + best_thresh, :428-437) and the <-f name>_*.csv score files are written
 // (:471, manageAllPerformances); every file is scored against its `label` field (:462-463).
@@ -68,7 +68,8 @@ int main(int argc, char** argv) {
                " -o <out.pcd>                   (writes the coloured voxel cloud) \n\t"
                " --labels <file>                (writes per-point uint32 region ids) \n\t"
                " --gpu <id>                     (HIP device, default 0) \n\t"
-               " --stream <depth>               (with -t and --labels: files through the frame pipeline, <depth> in flight) \n",
+               " --stream <depth>               (with -t and --labels: files through the frame pipeline, <depth> in flight) \n\t"
+               " --refine <iterations>          (refineSupervoxels as main() does with 3, :369-375; with -o also <out.pcd>.refined) \n",
                argv[0]);
         return 1;
     }
@@ -124,6 +125,8 @@ int main(int argc, char** argv) {
     prm.geom_metric = cvx ? F3DS_CONVEX_NORMALS_DIFF : F3DS_NORMALS_DIFF;
     prm.merging = ml ? F3DS_MANUAL_LAMBDA : (eq ? F3DS_EQUALIZATION : F3DS_ADAPTIVE_LAMBDA);
     prm.lambda = lambda; prm.bins = bin_num; prm.threshold = thresh; prm.fold_negative_z = 1;
+    int refine_itr = 0;
+    if (find_switch(argc, argv, "--refine")) parse(argc, argv, "--refine", refine_itr);
     int stream_depth = 0;
     if (find_switch(argc, argv, "--stream")) parse(argc, argv, "--stream", stream_depth);
     if (stream_depth > 0) {
@@ -191,7 +194,25 @@ int main(int argc, char** argv) {
         f3ds_result res;
         rc = f3ds_segment(ctx, pts.data(), n, 0, &prm, labels.data(), 0, &res);
         if (rc) { fprintf(stderr, "f3ds_segment: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
-        printf("Found %u supervoxels\nGetting supervoxel adjacency...\nSegmentation initialization...\n", res.n_supervoxels);
+        printf("Found %u supervoxels\nGetting supervoxel adjacency...\n", res.n_supervoxels);
+        if (refine_itr > 0) {                                   // :369-375: feeds the viewer only; here the refined labelled voxel cloud can be written
+            printf("Refining supervoxels...\n");
+            rc = f3ds_refine_supervoxels(ctx, refine_itr);
+            size_t nsv = 0, nvx = 0;
+            if (!rc) rc = f3ds_get_refined_supervoxels(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &nsv);
+            if (!rc) rc = f3ds_get_refined_voxels(ctx, nullptr, nullptr, 0, &nvx);
+            if (rc) { fprintf(stderr, "f3ds_refine_supervoxels: %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
+            printf("%zu supervoxels after %d refinement iterations\n", nsv, refine_itr);
+            if (!out_pcd.empty()) {
+                std::vector<float> xyz(nvx * 3); std::vector<uint32_t> col(nvx), lab(nvx); size_t m = 0;
+                rc = f3ds_get_voxel_centroid_cloud(ctx, xyz.data(), col.data(), nullptr, nvx, &m);
+                if (!rc) rc = f3ds_get_refined_voxels(ctx, lab.data(), nullptr, nvx, &m);
+                std::string suffix = file_list.size() > 1 ? "." + std::filesystem::path(file).stem().string() : "";
+                if (!rc) rc = f3ds_pcd_write((out_pcd + suffix + ".refined").c_str(), xyz.data(), col.data(), lab.data(), nvx, 1);
+                if (rc) { fprintf(stderr, "writing %s.refined: %s\n", out_pcd.c_str(), f3ds_strerror(rc)); f3ds_destroy(ctx); return 1; }
+            }
+        }
+        printf("Segmentation initialization...\n");
         if (ml || al) DEBUG("Lambda: %f\n", res.lambda);
         if (!thresh_specified) {                                // all_thresh + best_thresh (:428-437)
             std::vector<float> ts(4096); std::vector<f3ds_performance> ps(4096);

@@ -149,6 +149,25 @@ def test_cli_on_fixture(P, oracle, tmp_path):
     assert np.array_equal(cloud[:, 3].copy().view(np.uint32), oc)
 
 
+def test_cli_refine_flag(P, oracle, tmp_path):
+    """--refine 3 (main() calls refineSupervoxels(3, ...), :371): the count it prints and the labelled voxel cloud it writes
+    are the oracle's."""
+    import subprocess
+    from conftest import FIXTURE_PCD
+    exe = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd", "supervoxel_clustering")
+    out = str(tmp_path / "seg.pcd")
+    r = subprocess.run([exe, "--CVX", "--AL", "-t", "0.2", "-p", FIXTURE_PCD, "-o", out, "--refine", "3"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    pts = P.read_pcd(FIXTURE_PCD)
+    rc, olab, ores, oh = oracle.segment(pts, P.launch_params())
+    want = oh.refine(3)
+    assert "Refining supervoxels...\n%d supervoxels after 3 refinement iterations" % len(want["label"]) in r.stdout
+    cloud, lab = P.read_pcd(out + ".refined", with_labels=True)
+    assert np.array_equal(lab, want["voxel_label"])
+    xyz = oh.get("VOXEL_XYZ").reshape(-1, 3)
+    assert np.array_equal(cloud[:, :3].view(np.uint32), xyz.view(np.uint32))
+
+
 def test_batch_of_frames_matches_single_calls(P, oracle):
     """f3ds_segment_batch: one context per frame, one merge dispatch for all of them."""
     names = ["rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags", "rgbd_160x120"]
