@@ -2,78 +2,104 @@
 """bench.py -- Mpoints/s segmented end-to-end on synthetic 1M-point RGB-D frames (BASELINE.json).
 
 A *step* is one pass of the whole hot path (voxelise -> normals -> seeds -> sweeps -> adjacency ->
-merge -> per-point labels) over one 1,000,000-point XYZRGBA frame that is already resident in
-HBM when the timed region starts (config 2 of BASELINE.md: 1000x1000 pinhole frame, 3 % NaN,
-flags ``-v 0.008 -s 0.08 --AL --CVX -t 0.2``).  Frames are independent, and a single frame holds
-two inherently sequential pieces (16 Gauss-Seidel sweeps, ~2800 dependent merges), so the steps
-are issued ``--batch`` frames at a time through ``f3ds_segment_batch`` -- every kernel of the path
-is then ONE dispatch for the whole batch (grid.y = frame; the merge loops run one workgroup per
-frame) -- and ``--groups`` such calls are in flight from host threads so that one batch's wide
-kernels overlap another batch's merge dispatch.  Every step still runs the complete path on its
-own frame; the JSON also reports the latency of a single frame with nothing else in flight.
+merge -> per-point labels) over ONE BATCH OF 64 DISTINCT 1,000,000-point XYZRGBA frames per GPU --
+BASELINE.json config 5's batch (64 frames, seeds 1000..1063 on rank 0; rank r takes seeds
+1000+64r..) on every GPU, each frame the 1000x1000 pinhole frame of config 2 with 3 % NaN,
+flags ``-v 0.008 -s 0.08 --AL --CVX -t 0.2`` -- resident in HBM when the timed region starts.
+Frames are independent, and a single frame holds two inherently sequential pieces (16 Gauss-Seidel
+sweeps, ~2400 dependent merges), so the frames of the K timed steps are issued through
+``f3ds_segment_batch`` in calls of up to ``--batch`` frames (every kernel of the path is then ONE
+dispatch for the whole call, grid.y = frame) and ``--groups`` such calls are in flight from host
+threads so that one call's wide kernels overlap another call's merge dispatch.  Every frame of
+every step runs the complete path; nothing is cached between steps.
 
-N > 1 (launched by ``python -m torch.distributed.run``): one process per GPU, each rank segments
-its own frames (weak scaling, no data-path collective); the label output is one RCCL gather of
-the uint32 label buffers to rank 0 per frame.
+``--gpus N`` with N > 1 and no torchrun environment: this process starts the N ranks itself (a child
+``python -m torch.distributed.run``; nothing here touches the GPU before that).  One process per GPU,
+every rank runs its own 64 frames per step (weak scaling, no data-path collective); the label
+output of a step is ONE RCCL gather of the step's [64, 1M] uint32 label block to rank 0, issued in
+step order from a dedicated thread while later steps run.
 
 The JSON line also carries
+  value_host_io -- the same loop with the frames in pinned host memory and the labels delivered to
+                  pinned host memory (PCIe both ways inside the timed region: what SURVEY.md 8d
+                  defines); `value` itself is the HBM-resident rate;
   roofline     -- dominant kernel by device time (HIP events recorded on the batch's stream inside
                   libf3ds around each stage): achieved = 20 B/point x points per launch / mean launch
-                  duration, against the 8 TB/s HBM3E peak;
+                  duration, against the 8 TB/s HBM3E peak; `whole_path` = the same for the timed
+                  region as a whole, with the PMC-measured HBM traffic of all kernels of the path;
   cpu_baseline -- the CPU oracle (single thread, kind "port": the reference needs PCL/OpenCV and
                   cannot be built here) on one frame of the same workload, rank 0 at N=1 only.
 """
 import argparse
-import ctypes
-import importlib
 import json
 import os
-import queue
+import subprocess
 import sys
-import threading
 import time
 
-# HIP maps streams onto 4 hardware queues by default; a frame's merge kernel is one long
-# single-workgroup launch, so with more frames in flight than queues a second frame's short kernels
-# would wait behind it.  Must be set before the HIP runtime starts (22.8 -> 44 Mpoints/s in round 1).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
+FRAMES_PER_STEP = 64              # BASELINE.json config 5: a batch of 64 synthetic 1M-point frames
 STAGES = ["voxelise", "neighbours+normals", "seeds", "sweeps", "summaries+adjacency+weights", "merge", "labels"]
-# the kernel that dominates each stage (rocprofv3 --kernel-trace names in profiles/)
-STAGE_KERNEL = {"voxelise": "k_batched<d_radix_scatter>", "neighbours+normals": "k_batched<d_normals>", "seeds": "k_batched<d_seed_nn>", "sweeps": "k_batched<d_sweep_R>",
-                "summaries+adjacency+weights": "k_batched<d_sv_fill>", "merge": "k_batched<d_merge_lds_t<true>>", "labels": "k_batched<d_point_labels>"}
 ALG_BYTES_PER_POINT = 20          # 16 B read of {x,y,z,rgba} + 4 B label write (SURVEY.md 8d)
 HBM_PEAK_GBS = 8000.0             # MI355X HBM3E (guides/MI355X_MICROARCH.md)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3072)
-    ap.add_argument("--warmup", type=int, default=768)
-    ap.add_argument("--batch", type=int, default=192, help="frames per f3ds_segment_batch call")
+    ap.add_argument("--steps", type=int, default=48, help="timed steps; a step = 64 distinct 1M-point frames per GPU")
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=192, help="most frames per f3ds_segment_batch call")
     ap.add_argument("--groups", type=int, default=4, help="batch calls in flight per GPU (libf3ds runs up to four on distinct hardware queues)")
-    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames to cycle through")
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--height", type=int, default=1000)
+    ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the pinned-host-in / host-out pass (default min(steps, 12); 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    import numpy as np
+
+def spawn_ranks(args):
+    """--gpus N without a torchrun environment: start the N ranks as a CHILD job and relay its exit code.  This parent
+    never imports torch or touches HIP (a process that has initialised the GPU must not be replaced or re-launched)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    # HIP maps streams onto 4 hardware queues by default; libf3ds keeps one stream per queue for its batch calls.
+    # Must be set before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+
+    import numpy as np      # noqa
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # development: F3DS_BENCH_FORCE_DIST=1 takes the RCCL path (process group, label gather, barrier) with one rank too
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: running %d rank(s)" % (args.gpus, world, world), file=sys.stderr, flush=True)
+    # development: F3DS_BENCH_FORCE_DIST=1 takes the RCCL path (process group, per-step label gather, barrier) with one rank too
     dist_on = world > 1 or bool(os.environ.get("F3DS_BENCH_FORCE_DIST"))
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "RANK" not in os.environ:      # single forced rank without torchrun
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libf3ds has no CPU fallback")
@@ -86,66 +112,53 @@ def main():
     if os.environ.get("F3DS_BENCH_THRESHOLD"):                    # development only: what-if runs (the JSON line then names the threshold)
         prm.threshold = float(os.environ["F3DS_BENCH_THRESHOLD"])
     npts = args.width * args.height
+    FPS = FRAMES_PER_STEP
 
-    # synthetic frames -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
-    frames_host = [P.synth_frame(0, 1000 + rank * 64 + i, args.width, args.height, 30) for i in range(args.frames)]
+    # 64 distinct synthetic frames per rank -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
+    seeds = [1000 + rank * FPS + i for i in range(FPS)]
+    with ThreadPoolExecutor(8) as ex:
+        frames_host = list(ex.map(lambda s: P.synth_frame(0, s, args.width, args.height, 30), seeds))
     frames_dev = [torch.from_numpy(f).to(dev) for f in frames_host]
-    # frames in flight = groups x batch: every group segments `batch` frames per f3ds_segment_batch call
-    # (wide stages on one stream per frame, all merge loops of the batch in ONE dispatch); `groups` such
-    # calls run concurrently from host threads so one batch's wide stages overlap another's merge loops.
     nbatch, ngroups = max(1, args.batch), max(1, args.groups)
-    if args.steps < nbatch * ngroups:       # few steps: spread them over the groups instead of leaving groups idle
-        nbatch = max(1, -(-args.steps // ngroups))
-    nstreams = nbatch * ngroups
     ctxs = [[P.Context(local_rank) for _ in range(nbatch)] for _ in range(ngroups)]
-    # one contiguous label block per group: the batch's label output is ONE RCCL gather (nbatch x 4 MB per rank)
-    label_blocks = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(ngroups)]
-    label_bufs = [[label_blocks[g][i] for i in range(nbatch)] for g in range(ngroups)]
-    gather_list = [torch.empty((nbatch, npts), dtype=torch.int32, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None
+    # label output: a ring of per-step blocks [64, npts]; a step's block is ONE RCCL gather (64 x 4 MB per rank)
+    n_blocks = -(-(nbatch * ngroups) // FPS) + 2
+    label_blocks = [torch.empty((FPS, npts), dtype=torch.int32, device=dev) for _ in range(n_blocks)]
+    gather_list = [torch.empty((FPS, npts), dtype=torch.int32, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None
+    gather_stream = torch.cuda.Stream(device=dev) if dist_on else None
     torch.cuda.synchronize()
 
     stage_ms = [0.0] * 7
-    batches_done, frames_done = [0], [0]
-    stage_lock = threading.Lock()
-    errors = []
+    calls_done, frames_done = [0], [0]
+    stat_lock = threading.Lock()
+    mode = {"record": False, "host": False}
+    host_frames, host_labels = [], []
 
-    def run_steps(count, record):
-        q = queue.Queue()
-        for s0 in range(0, count, nbatch):
-            q.put(list(range(s0, min(count, s0 + nbatch))))
+    def run_batch(g, f0, f1):
+        torch.cuda.set_device(local_rank)
+        k = f1 - f0
+        if mode["host"]:
+            pts = [host_frames[f % FPS].data_ptr() for f in range(f0, f1)]
+            out = [host_labels[(f // FPS) % n_blocks][f % FPS].data_ptr() for f in range(f0, f1)]
+            P.segment_batch(ctxs[g][:k], pts, prm, labels_out=out, n=[npts] * k, raw_host=True)
+        else:
+            pts = [frames_dev[f % FPS].data_ptr() for f in range(f0, f1)]
+            out = [label_blocks[(f // FPS) % n_blocks][f % FPS].data_ptr() for f in range(f0, f1)]
+            P.segment_batch(ctxs[g][:k], pts, prm, labels_out=out, n=[npts] * k, on_device=True)
+        if mode["record"]:      # ms_stage is the device time of each stage of the whole call (HIP events on the call's stream)
+            with stat_lock:
+                for j in range(7):
+                    stage_ms[j] += ctxs[g][0].result.ms_stage[j]
+                calls_done[0] += 1
+                frames_done[0] += k
 
-        def worker(g):
-            torch.cuda.set_device(local_rank)
-            while True:
-                try:
-                    steps = q.get_nowait()
-                except queue.Empty:
-                    return
-                try:
-                    k = len(steps)
-                    P.segment_batch(ctxs[g][:k], [frames_dev[s % len(frames_dev)].data_ptr() for s in steps], prm,
-                                    labels_out=[label_bufs[g][i].data_ptr() for i in range(k)], n=[npts] * k, on_device=True)
-                    if dist_on:     # label output of this batch: one RCCL gather of the whole label block to rank 0
-                        with stage_lock:
-                            B.gather_label_block(label_blocks[g], dist, gather_list, dst=0)
-                            torch.cuda.current_stream().synchronize()      # the block is reused by this group's next batch (on libf3ds' own stream)
-                    if record:      # ms_stage is the device time of each stage of the whole batch (HIP events on the batch stream)
-                        with stage_lock:
-                            for j in range(7):
-                                stage_ms[j] += ctxs[g][0].result.ms_stage[j]
-                            batches_done[0] += 1
-                            frames_done[0] += k
-                except Exception as e:   # noqa
-                    errors.append(e)
-                    return
+    def gather_step(s):         # label output of step s: one RCCL gather of its label block to rank 0 (in step order on every rank)
+        torch.cuda.set_device(local_rank)
+        with torch.cuda.stream(gather_stream):
+            B.gather_label_block(label_blocks[s % n_blocks], dist, gather_list, dst=0)
+        gather_stream.synchronize()     # the ring slot is written again by a later step (on libf3ds' own streams)
 
-        threads = [threading.Thread(target=worker, args=(g,)) for g in range(ngroups)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+    pipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, gather_step if dist_on else None)
 
     def barrier():
         if dist_on:
@@ -154,55 +167,88 @@ def main():
 
     # set-up, not warm-up: every context grows its device scratch on first use (hipMalloc), so each is used once before
     # the W warm-up steps, however small W is; the timed region never allocates
-    run_steps(nbatch * ngroups, False)
+    def use_every_context():
+        ts = [threading.Thread(target=run_batch, args=(g, g * nbatch, (g + 1) * nbatch)) for g in range(ngroups)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    use_every_context()
     barrier()
-    run_steps(args.warmup, False)
+    pipe.run(args.warmup)
     barrier()
     if os.environ.get("F3DS_BENCH_MEMINFO"):                      # development: HBM in use after warm-up (contexts are grow-only)
         free, total = torch.cuda.mem_get_info(dev)
         print("rank %d: %.1f GB of %.1f GB HBM in use" % (rank, (total - free) / 2**30, total / 2**30), file=sys.stderr, flush=True)
+    mode["record"] = True
     t0 = time.perf_counter()
-    run_steps(args.steps, True)
+    plan = pipe.run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    mode["record"] = False
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the same loop, frames from pinned host memory, labels into pinned host memory (PCIe inside the timed region)
+    hio_steps = min(args.steps, 12) if args.host_io_steps < 0 else args.host_io_steps
+    host_io = None
+    if hio_steps > 0:
+        host_frames.extend(torch.from_numpy(f).pin_memory() for f in frames_host)
+        host_labels.extend(torch.empty((FPS, npts), dtype=torch.int32).pin_memory() for _ in range(n_blocks))
+        mode["host"] = True
+        hpipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, None)
+        use_every_context()                                 # contexts allocate their upload buffers once
+        barrier()
+        th = time.perf_counter()
+        hpipe.run(hio_steps)
+        barrier()
+        el_h = time.perf_counter() - th
+        if dist_on:
+            t = torch.tensor([el_h], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_h = float(t.item())
+        host_io = {"value": round(world * hio_steps * FPS * npts / el_h / 1e6, 3), "unit": "Mpoints/s", "steps": hio_steps,
+                   "what": "same loop, frames in pinned host memory, labels delivered to pinned host memory (no RCCL gather in this pass)"}
+        mode["host"] = False
+
     # single-frame latency (one stream, nothing else in flight) for the record
     barrier()
     tl = time.perf_counter()
     for s in range(3):
-        ctxs[0][0].segment(frames_dev[s % len(frames_dev)].data_ptr(), prm, labels_out=label_bufs[0][0].data_ptr(), n=npts, on_device=True)
+        ctxs[0][0].segment(frames_dev[s].data_ptr(), prm, labels_out=label_blocks[0][0].data_ptr(), n=npts, on_device=True)
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
     res = ctxs[0][0].result
 
     if rank == 0:
-        value = world * args.steps * npts / elapsed / 1e6
-        mean_stage = [m / max(1, batches_done[0]) for m in stage_ms]       # per batched launch sequence
-        frames_per_launch = frames_done[0] / max(1, batches_done[0])
-        # The dominant KERNEL is the merge loop: 42 % of all device time in profiles/r1_kernel_stats.csv, one launch
-        # per batch, so its launch duration is exactly the 'merge' stage measured live below.  (The 'sweeps' stage
-        # can be as long, but it is 64 launches of four different kernels.)
+        total_frames = args.steps * FPS
+        value = world * total_frames * npts / elapsed / 1e6
+        mean_stage = [m / max(1, calls_done[0]) for m in stage_ms]       # per batched launch sequence
+        frames_per_launch = frames_done[0] / max(1, calls_done[0])
+        # The dominant KERNEL: the merge loop is ONE launch per call, so its launch duration is exactly the 'merge' stage
+        # measured live (HIP events on the call's stream).  The other stages are sequences of many launches of several kernels;
+        # the longest of their kernels (profiles/r2_kernel_stats.csv) is shorter than the merge launch.
         dom = STAGES.index("merge")
         dom_ms = mean_stage[dom]
-        # one launch of the dominant kernel processes `frames_per_launch` frames (grid.y = frame)
         achieved = ALG_BYTES_PER_POINT * npts * frames_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))
-            kname = STAGE_KERNEL[STAGES[dom]].split("<")[1].rstrip(">")      # d_merge_lds_t, d_sweep_R, ...
-            if kname in pm["kernels"]:
-                traffic = int(pm["kernels"][kname]["hbm_bytes_per_frame"] * frames_per_launch)
+        traffic = path_traffic = None
+        try:        # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")))
+            traffic = int(pm["kernels"]["d_merge_lds_t"]["hbm_bytes_per_frame"] * frames_per_launch)
+            path_traffic = int(pm["whole_path_hbm_bytes_per_frame"])
         except Exception:
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": STAGE_KERNEL[STAGES[dom]], "stage": STAGES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            pass
+        whole = {"achieved": round(ALG_BYTES_PER_POINT * value * 1e6 / world / 1e9, 3), "unit": "GB/s", "frac": round(ALG_BYTES_PER_POINT * value * 1e6 / world / 1e9 / HBM_PEAK_GBS, 6),
+                 "algorithmic_bytes_per_frame": ALG_BYTES_PER_POINT * npts, "traffic_per_frame": path_traffic,
+                 "wasted_ratio": round(path_traffic / (ALG_BYTES_PER_POINT * npts), 2) if path_traffic else None}
+        roofline = {"bound": "hbm", "kernel": "k_batched<d_merge_lds_t<true>>", "stage": "merge", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                    "launch_ms": round(dom_ms, 4), "frames_per_launch": frames_per_launch,
+                    "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                     "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_POINT * npts * frames_per_launch),
-                    "whole_path_achieved_GBps": round(ALG_BYTES_PER_POINT * npts * frames_per_launch / (sum(mean_stage) * 1e-3) / 1e9, 3) if sum(mean_stage) > 0 else None,
-                    "stage_ms": {STAGES[i]: round(mean_stage[i], 4) for i in range(7)}}
+                    "whole_path": whole,
+                    "stage_ms_per_call": {STAGES[i]: round(mean_stage[i], 4) for i in range(7)}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from conftest import CpuChecker
@@ -211,18 +257,33 @@ def main():
             rc, olab, ores, oh = ora.segment(frames_host[0], prm)
             cpu_s = time.perf_counter() - tc
             assert rc == 0
+            # what a user of the reference's main() waits for on top of the label path: refineSupervoxels(3) (viewer only) and a
+            # second VCCS run on the label-coloured cloud (/root/reference/src/supervoxel_clustering.cpp:369-400)
+            tm = time.perf_counter()
+            oh.refine(3)
+            p0 = prm.copy(); p0.threshold = 0.0
+            rc2, _, _, oh2 = ora.segment(frames_host[1], p0)
+            main_s = cpu_s + time.perf_counter() - tm
+            oh2.close()
             cpu = {"value": round(npts / cpu_s / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
                    "sample": "1 frame (%d points) of the same workload through oracle/libf3ds_oracle.so, %.2f s" % (npts, cpu_s),
+                   "as_main_runs_it": {"value": round(npts / main_s / 1e6, 4), "seconds": round(main_s, 2),
+                                       "what": "label path + refineSupervoxels(3) + a second VCCS extract (the truth cloud), as main() does per file"},
+                   "note": "the port is faster than the reference would be: hash-set contains() instead of the O(E) scan, cached mean_color",
                    "host_cpus": os.cpu_count()}
             oh.close()
         line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "single synthetic %dx%d (%d-point) XYZRGBA frame per step, -v 0.008 -s 0.08 --AL --CVX -t %g" % (args.width, args.height, npts, prm.threshold),
-                           "frames_in_flight_per_gpu": nstreams, "setup": "one untimed pass over all contexts (scratch allocation) before the warm-up steps", "batch": nbatch, "concurrent_batches": ngroups, "distinct_frames": args.frames, "parallelism": "frames sharded one per GPU" if world > 1 else "1 GPU",
-                           "label_gather": "one RCCL gather of the batch's label block (batch x 4 MB per rank) to rank 0 per batch" if dist_on else "none",
+                "config": {"workload": "step = batch of %d distinct synthetic %dx%d (%d-point) XYZRGBA frames per GPU (BASELINE config 5's batch, seeds 1000+64*rank..), "
+                                       "-v 0.008 -s 0.08 --AL --CVX -t %g, frames resident in HBM" % (FPS, args.width, args.height, npts, prm.threshold),
+                           "frames_per_step_per_gpu": FPS, "points_per_step": world * FPS * npts, "frames_timed": world * total_frames,
+                           "batch_calls": len(plan), "frames_per_call": round(total_frames / max(1, len(plan)), 1), "concurrent_calls": ngroups, "distinct_frames_per_gpu": FPS,
+                           "setup": "one untimed pass over all contexts (scratch allocation) before the warm-up steps",
+                           "parallelism": ("%d ranks, one per GPU, every rank its own frames" % world) if world > 1 else "1 GPU",
+                           "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
-                "single_stream_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
+                "value_host_io": host_io, "single_frame_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     for grp in ctxs:
         for c in grp:

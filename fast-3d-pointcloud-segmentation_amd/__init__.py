@@ -253,6 +253,7 @@ class Context:
             ptr, count = ctypes.c_void_p(int(points)), int(n)
             out_ptr = ctypes.c_void_p(int(labels_out)) if labels_out is not None else None
             _check(self.lib, self.lib.f3ds_segment(self.handle, ptr, count, 1, ctypes.byref(params), out_ptr, 1, ctypes.byref(self.result)))
+            self._n = count
             return None
         pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
         labels = np.empty(len(pts), np.uint32)
@@ -262,7 +263,7 @@ class Context:
         return labels
 
     def recluster(self, params):
-        labels = np.empty(self._n, np.uint32)
+        labels = np.empty(int(self.result.n_points) or self._n, np.uint32)      # f3ds_recluster writes one label per point of the frame
         _check(self.lib, self.lib.f3ds_recluster(self.handle, ctypes.byref(params), labels.ctypes.data, 0, ctypes.byref(self.result)))
         return labels
 
@@ -436,19 +437,23 @@ class FrameStream:
             yield self.next()
 
 
-def segment_batch(ctxs, points, params, labels_out=None, n=None, on_device=False):
+def segment_batch(ctxs, points, params, labels_out=None, n=None, on_device=False, raw_host=False):
     """Segment len(ctxs) independent frames at once (one context per frame, all on one GPU).
     Host mode: points = list of (N_i,4) float32 arrays, returns a list of label arrays.
-    Device mode: points / labels_out = lists of device pointers, n = list of point counts."""
+    Device mode (on_device): points / labels_out = lists of device pointers, n = list of point counts.
+    raw_host: the same with host pointers (e.g. pinned buffers of the caller): PCIe both ways inside the call."""
     lib = load_library()
     k = len(ctxs)
     vp = ctypes.c_void_p
     handles = (vp * k)(*[c.handle for c in ctxs])
     results = (Result * k)()
-    if on_device:
+    if on_device or raw_host:
+        where = 1 if on_device else 0
         pp = (vp * k)(*[vp(int(p)) for p in points]); lp = (vp * k)(*[vp(int(p)) for p in labels_out])
         cnt = (ctypes.c_size_t * k)(*[int(x) for x in n])
-        _check(lib, lib.f3ds_segment_batch(handles, k, pp, cnt, 1, ctypes.byref(params), lp, 1, results))
+        _check(lib, lib.f3ds_segment_batch(handles, k, pp, cnt, where, ctypes.byref(params), lp, where, results))
+        for c, x in zip(ctxs, n):
+            c._n = int(x)
         out = None
     else:
         arrs = [np.ascontiguousarray(p, np.float32).reshape(-1, 4) for p in points]

@@ -1,8 +1,10 @@
 """Frame sharding for multi-GPU batches (BASELINE.json config 5): independent frames, one process
-per GPU, frame i -> rank i mod world; the only exchange is the label output, gathered to rank 0.
+per GPU; the only exchange is the label output, gathered to rank 0 -- one collective per 64-frame step.
 
-Kept free of GPU calls so the world_size-2 gloo test can drive it on CPU tensors; on the GPU box the
-same functions run over RCCL (torch backend "nccl")."""
+Kept free of GPU calls so the world_size-2 gloo tests can drive it on CPU tensors; on the GPU box the
+same functions run over RCCL (torch backend "nccl").  The C++ counterpart (one host thread per GPU, labels
+to GPU 0 with librccl) is csrc/f3ds_multi.cpp."""
+import threading
 
 
 def frames_of_rank(n_frames, rank, world):
@@ -10,36 +12,137 @@ def frames_of_rank(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def gather_labels(local_labels, dist, dst=0):
+def gather_labels(local_labels, dist, dst=0, n_points=None, device="cpu"):
     """local_labels: list of 1-D int32 tensors (one per local frame, equal length across ranks for
     the synthetic batch).  Returns on `dst` a dict frame_index -> tensor, elsewhere None.  One
-    gather per local frame slot: world x 4 MB for 1M-point frames, each peer over its own xGMI link."""
+    gather per local frame slot: world x 4 MB for 1M-point frames, each peer over its own xGMI link.
+    A rank may hold no frame at all (fewer frames than ranks): it pads with zeros of the common length."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     out = {} if rank == dst else None
-    n_slots = torch.tensor([len(local_labels)], dtype=torch.int64, device=local_labels[0].device if local_labels else "cpu")
-    slots = [torch.zeros_like(n_slots) for _ in range(world)]
-    dist.all_gather(slots, n_slots)
-    max_slots = int(max(int(s.item()) for s in slots))
-    for k in range(max_slots):
-        mine = local_labels[k] if k < len(local_labels) else torch.zeros_like(local_labels[0])
+    if local_labels:
+        device = local_labels[0].device
+        n_points = int(local_labels[0].numel())
+    meta = torch.tensor([len(local_labels), n_points or 0], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    slots = [int(m[0].item()) for m in metas]
+    length = max(int(m[1].item()) for m in metas)
+    for k in range(max(slots)):
+        mine = local_labels[k] if k < len(local_labels) else torch.zeros(length, dtype=torch.int32, device=device)
         bufs = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
         dist.gather(mine, bufs, dst=dst)
         if rank == dst:
             for r in range(world):
-                if k < int(slots[r].item()):
+                if k < slots[r]:
                     out[r + k * world] = bufs[r]
     return out
 
 
 def gather_label_block(block, dist, bufs=None, dst=0):
-    """The form bench.py uses: the label output of a whole batch (a contiguous [frames, points] int32 block per rank)
-    goes to rank `dst` in ONE collective.  `bufs` (rank dst only): preallocated list of world blocks, reused
-    across batches.  Returns the list on dst, None elsewhere.  Collectives on one communicator must not be issued
-    concurrently from several threads: callers with several batches in flight serialise this call."""
+    """The label output of one step (a contiguous [frames, points] int32 block per rank) goes to rank `dst` in ONE
+    collective.  `bufs` (rank dst only): preallocated list of world blocks, reused across steps.  Returns the list on
+    dst, None elsewhere.  Collectives on one communicator must be issued in the same order on every rank and never
+    concurrently from several threads: StepPipeline below owns that."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     if rank == dst and bufs is None:
         bufs = [torch.empty_like(block) for _ in range(world)]
     dist.gather(block, bufs if rank == dst else None, dst=dst)
     return bufs if rank == dst else None
+
+
+def plan_batches(total_frames, max_batch, groups):
+    """Cut `total_frames` consecutive frames into batch calls of at most `max_batch` frames such that the number of calls is a
+    multiple of `groups` (no host thread idles in the last round) and the calls are as equal as possible.
+    Returns [(first, last+1), ...]."""
+    if total_frames <= 0:
+        return []
+    max_batch, groups = max(1, max_batch), max(1, groups)
+    calls = -(-total_frames // max_batch)
+    if total_frames >= groups:
+        calls = -(-calls // groups) * groups
+    size, extra = divmod(total_frames, calls)
+    out, f = [], 0
+    for i in range(calls):
+        k = size + (1 if i < extra else 0)
+        if k:
+            out.append((f, f + k))
+            f += k
+    return out
+
+
+class StepPipeline:
+    """K steps of `frames_per_step` independent frames on one rank.  `groups` host threads run batch calls (frame ranges
+    from plan_batches, which need not respect step boundaries) through `run_batch(group, first, last)`; whenever every
+    frame of step s is done -- in step order, the same order on every rank -- `on_step(s)` runs on a dedicated thread
+    (the label gather of that step).  A step's label block is one of `n_blocks` ring slots: a batch that would write
+    into the slot of a step not gathered yet waits.  Exceptions of any thread are re-raised by run()."""
+
+    def __init__(self, frames_per_step, max_batch, groups, n_blocks, run_batch, on_step=None):
+        self.fps, self.max_batch, self.groups, self.n_blocks = frames_per_step, max_batch, groups, n_blocks
+        self.run_batch, self.on_step = run_batch, on_step
+        if on_step is not None and n_blocks * frames_per_step < max_batch + frames_per_step:
+            raise ValueError("label ring too small for one batch call")
+
+    def block_of(self, frame):
+        return (frame // self.fps) % self.n_blocks, frame % self.fps
+
+    def run(self, n_steps):
+        total = n_steps * self.fps
+        plan = plan_batches(total, self.max_batch, self.groups)
+        cv = threading.Condition()
+        state = {"next": 0, "done": [0] * n_steps, "gathered": 0, "err": None}
+
+        def worker(g):
+            try:
+                while True:
+                    with cv:
+                        if state["err"] or state["next"] >= len(plan):
+                            return
+                        f0, f1 = plan[state["next"]]
+                        state["next"] += 1
+                        if self.on_step is not None:      # ring slot free again?
+                            last_step = (f1 - 1) // self.fps
+                            while state["gathered"] < last_step - self.n_blocks + 1 and not state["err"]:
+                                cv.wait()
+                            if state["err"]:
+                                return
+                    self.run_batch(g, f0, f1)
+                    with cv:
+                        for s in range(f0 // self.fps, (f1 - 1) // self.fps + 1):
+                            lo, hi = max(f0, s * self.fps), min(f1, (s + 1) * self.fps)
+                            state["done"][s] += hi - lo
+                        cv.notify_all()
+            except BaseException as e:      # noqa
+                with cv:
+                    state["err"] = state["err"] or e
+                    cv.notify_all()
+
+        def gatherer():
+            try:
+                for s in range(n_steps):
+                    with cv:
+                        while state["done"][s] < self.fps and not state["err"]:
+                            cv.wait()
+                        if state["err"]:
+                            return
+                    self.on_step(s)
+                    with cv:
+                        state["gathered"] = s + 1
+                        cv.notify_all()
+            except BaseException as e:      # noqa
+                with cv:
+                    state["err"] = state["err"] or e
+                    cv.notify_all()
+
+        threads = [threading.Thread(target=worker, args=(g,)) for g in range(self.groups)]
+        if self.on_step is not None:
+            threads.append(threading.Thread(target=gatherer))
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if state["err"]:
+            raise state["err"]
+        return plan

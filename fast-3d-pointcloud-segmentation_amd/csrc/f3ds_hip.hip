@@ -140,11 +140,25 @@ struct f3ds_ctx {
 
 namespace {
 
+// A recorded, not yet flushed kernel call holds raw device pointers in its argument blob: a buffer such a call refers to
+// must not be freed and reallocated before the flush (the dispatch would write into freed memory).  Checked on every regrow.
+bool referenced_by_pending_calls(const f3ds_ctx* c, const Buf& b) {
+    const uintptr_t lo = (uintptr_t)b.p, hi = lo + b.cap;
+    for (size_t off = 0; off + 8 <= c->blob.size(); off += 8) {
+        uint64_t w; memcpy(&w, c->blob.data() + off, 8);
+        if (w >= lo && w < hi) return true;
+    }
+    return false;
+}
 template <class T>
-int ensure(Buf& b, size_t count, T** out) {
+int ensure(f3ds_ctx* c, Buf& b, size_t count, T** out) {
     size_t bytes = count * sizeof(T);
     if (bytes < 256) bytes = 256;
     if (b.cap < bytes) {
+        if (b.p && !c->cmds.empty() && referenced_by_pending_calls(c, b)) {
+            fprintf(stderr, "f3ds: internal error: regrowing a buffer that a recorded kernel call refers to\n");
+            return F3DS_ERR_LOGIC;
+        }
         if (b.p) { HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t want = bytes + bytes / 4 + 64;
         HIPCHECK(hipMalloc(&b.p, want));
@@ -153,7 +167,7 @@ int ensure(Buf& b, size_t count, T** out) {
     *out = reinterpret_cast<T*>(b.p);
     return F3DS_OK;
 }
-#define ENSURE(buf, T, count, ptr) do { int rc_ = ensure<T>(buf, (size_t)(count), &ptr); if (rc_) return rc_; } while (0)
+#define ENSURE(buf, T, count, ptr) do { int rc_ = ensure<T>(c, buf, (size_t)(count), &ptr); if (rc_) return rc_; } while (0)
 
 // Workgroups per frame of a wide kernel.  A launch covers all frames of the batch (grid.y = frame), so a frame gets its
 // share of a launch-wide budget of ~6 k workgroups (24 per CU) and the kernels loop (grid-stride) over the rest: with
@@ -497,6 +511,7 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
     const uint32_t E = c->E, S0 = c->S0;
     uint32_t *ea0, *eb0; ENSURE(c->ea0, uint32_t, E, ea0); ENSURE(c->eb0, uint32_t, E, eb0);
     uint32_t* evs;
+    { uint32_t* h; ENSURE(c->hist, uint32_t, (size_t)256 * (((size_t)E * 2 + RS_TILE - 1) / RS_TILE + 1), h); }      // also holds the 2E-delta sort of seg_cluster_front, recorded before this one is flushed
     rec<d_iota>(c, grid_for(E, 256), 0u, (uint32_t*)c->evals0.p, E);
     int rc = radix_sort(c, (uint64_t*)c->ekeys0.p, (uint32_t*)c->evals0.p, (uint64_t*)c->ekeys1.p, (uint32_t*)c->evals1.p, E, sort_bits, &c->eks, &evs);
     if (rc) return rc;
@@ -727,14 +742,18 @@ int f3ds_create(int device, f3ds_ctx** out) {
     HIPCHECK(hipSetDevice(device));
     f3ds_ctx* c = new f3ds_ctx;
     c->device = device;
-    HIPCHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    c->stream = c->own_stream;
-    for (auto& e : c->ev) HIPCHECK(hipEventCreate(&e));
-    HIPCHECK(hipMalloc((void**)&c->d_dc, sizeof(DevCounters)));
-    HIPCHECK(hipHostMalloc((void**)&c->h_dc, sizeof(DevCounters), hipHostMallocDefault));
-    HIPCHECK(hipMalloc((void**)&c->d_grid, sizeof(GridInfo)));
-    HIPCHECK(hipHostMalloc((void**)&c->h_grid, sizeof(GridInfo), hipHostMallocDefault));
-    HIPCHECK(hipMalloc((void**)&c->d_sgrid, sizeof(SeedGrid)));
+    const int rc = [c]() -> int {
+        HIPCHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        for (auto& e : c->ev) HIPCHECK(hipEventCreate(&e));
+        HIPCHECK(hipMalloc((void**)&c->d_dc, sizeof(DevCounters)));
+        HIPCHECK(hipHostMalloc((void**)&c->h_dc, sizeof(DevCounters), hipHostMallocDefault));
+        HIPCHECK(hipMalloc((void**)&c->d_grid, sizeof(GridInfo)));
+        HIPCHECK(hipHostMalloc((void**)&c->h_grid, sizeof(GridInfo), hipHostMallocDefault));
+        HIPCHECK(hipMalloc((void**)&c->d_sgrid, sizeof(SeedGrid)));
+        return F3DS_OK;
+    }();
+    if (rc) { c->stream = c->own_stream; f3ds_destroy(c); return rc; }      // a half-built context is released, not leaked
     memset(c->h_grid, 0, sizeof(GridInfo));
     memset(&c->res, 0, sizeof c->res);
     *out = c;
@@ -744,7 +763,7 @@ int f3ds_create(int device, f3ds_ctx** out) {
 void f3ds_destroy(f3ds_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     Buf* bufs = &c->pts;
     const size_t nb = (reinterpret_cast<char*>(&c->rincl) - reinterpret_cast<char*>(&c->pts)) / sizeof(Buf) + 1;
     for (size_t i = 0; i < nb; ++i) if (bufs[i].p) (void)hipFree(bufs[i].p);

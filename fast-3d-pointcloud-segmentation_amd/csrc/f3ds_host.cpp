@@ -156,7 +156,9 @@ extern "C" int f3ds_pcd_read(const char* path, void* points16, uint32_t* labels,
         }
     }
     if (mode.empty() || fields.empty()) return F3DS_ERR_IO;
-    if (!have_points) npoints = w * h;
+    if (pos > data.size()) pos = data.size();      // "DATA binary" as the last bytes of the file, no newline: no payload
+    for (const auto& f : fields) if (f.size <= 0 || f.count <= 0 || f.size > 8 || f.count > (1 << 20)) return F3DS_ERR_IO;
+    if (!have_points) { if (h && w > (size_t)-1 / h) return F3DS_ERR_IO; npoints = w * h; }
     if (width) *width = (uint32_t)w;
     if (height) *height = (uint32_t)h;
     if (n_out) *n_out = npoints;
@@ -175,6 +177,9 @@ extern "C" int f3ds_pcd_read(const char* path, void* points16, uint32_t* labels,
     }
     if (ix < 0 || iy < 0 || iz < 0) return F3DS_ERR_IO;
     for (int i : {ix, iy, iz}) if (fields[i].size != 4 || fields[i].type != 'F') return F3DS_ERR_IO;
+    // rgb / label are read as 4-byte words in the binary layouts
+    if (mode != "ascii") for (int i : {irgb, ilabel}) if (i >= 0 && fields[i].size * fields[i].count < 4) return F3DS_ERR_IO;
+    if (stride == 0 || npoints > (size_t)-1 / stride) return F3DS_ERR_IO;
     P16* out = (P16*)points16;
     auto put = [&](size_t i, const uint8_t* px, const uint8_t* py, const uint8_t* pz, const uint8_t* pc, const uint8_t* pl) {
         memcpy(&out[i].x, px, 4); memcpy(&out[i].y, py, 4); memcpy(&out[i].z, pz, 4);
@@ -184,7 +189,7 @@ extern "C" int f3ds_pcd_read(const char* path, void* points16, uint32_t* labels,
         if (labels) { uint32_t l = 0; if (pl) memcpy(&l, pl, 4); labels[i] = l; }
     };
     if (mode == "binary") {
-        if (data.size() - pos < stride * npoints) return F3DS_ERR_IO;
+        if (npoints > (data.size() - pos) / stride) return F3DS_ERR_IO;
         const uint8_t* base = data.data() + pos;
         for (size_t i = 0; i < npoints; ++i) {
             const uint8_t* r = base + i * stride;

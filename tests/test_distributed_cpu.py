@@ -26,7 +26,7 @@ def _worker(rank, world, port, n_frames, npts, q):
     mine = B.frames_of_rank(n_frames, rank, world)
     # stand-in labels: a deterministic function of (frame, point) so rank 0 can verify the routing
     local = [torch.from_numpy(((np.arange(npts, dtype=np.int64) * 7 + f * 1000003) % 97).astype(np.int32)) for f in mine]
-    got = B.gather_labels(local, dist, dst=0)
+    got = B.gather_labels(local, dist, dst=0, n_points=npts)
     if rank == 0:
         ok = sorted(got) == list(range(n_frames))
         for f, t in got.items():
@@ -36,7 +36,7 @@ def _worker(rank, world, port, n_frames, npts, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [4, 5])
+@pytest.mark.parametrize("n_frames", [4, 5, 1])      # 1: rank 1 holds no frame at all
 def test_two_rank_shard_and_gather(n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -100,3 +100,112 @@ def test_round_robin_partition():
         seen = sorted(i for r in range(world) for i in B.frames_of_rank(64, r, world))
         assert seen == list(range(64))
         assert all(len(B.frames_of_rank(64, r, world)) == 64 // world for r in range(world))
+
+
+def test_plan_batches_covers_every_frame_once():
+    B = __import__("importlib").import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    for total, mb, g in [(1280, 192, 4), (3072, 192, 4), (64, 192, 4), (1, 192, 4), (320, 192, 4), (5, 2, 3), (0, 8, 2), (768, 192, 4)]:
+        plan = B.plan_batches(total, mb, g)
+        assert [f for a, b in plan for f in range(a, b)] == list(range(total))
+        assert all(0 < b - a <= mb for a, b in plan)
+        if total >= g:
+            assert len(plan) % g == 0 or total < mb        # no host thread idles in the last round
+        if plan:
+            sizes = [b - a for a, b in plan]
+            assert max(sizes) - min(sizes) <= 1
+    assert len(B.plan_batches(1280, 192, 4)) == 8           # the driver's --steps 20: 8 calls of 160 frames
+
+
+def _pipeline_worker(rank, world, port, n_steps, q):
+    """bench.py's N > 1 loop on CPU tensors: batch calls that straddle step boundaries on three host threads, label blocks in
+    a ring, one gather per step in step order.  Rank 1 is slower than rank 0, so the ring must throttle and the order must hold."""
+    import threading
+    import time
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    B = importlib.import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    FPS, NP, NB = 4, 50, 4
+    blocks = [torch.zeros((FPS, NP), dtype=torch.int32) for _ in range(NB)]
+    bufs = [torch.empty((FPS, NP), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    seen, order = [], []
+    pipe_ref = []
+
+    def label(r, f):
+        return r * 100000 + f
+
+    def run_batch(g, f0, f1):
+        time.sleep(0.002 * (1 + rank * 3))
+        for f in range(f0, f1):
+            blk, slot = pipe_ref[0].block_of(f)
+            blocks[blk][slot].fill_(label(rank, f))
+
+    def on_step(s):
+        order.append(s)
+        got = B.gather_label_block(blocks[s % NB], dist, bufs, dst=0)
+        if rank == 0:
+            seen.append([[int(got[r][i, 0]) for i in range(FPS)] for r in range(world)])
+
+    pipe = B.StepPipeline(FPS, 6, 3, NB, run_batch, on_step)
+    pipe_ref.append(pipe)
+    plan = pipe.run(n_steps)
+    ok = order == list(range(n_steps)) and [f for a, b in plan for f in range(a, b)] == list(range(n_steps * FPS))
+    if rank == 0:
+        for s in range(n_steps):
+            ok &= seen[s] == [[label(r, s * FPS + i) for i in range(FPS)] for r in range(world)]
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_pipeline_gathers_every_step_in_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 13, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_step_pipeline_reraises_a_failing_batch():
+    B = __import__("importlib").import_module("fast-3d-pointcloud-segmentation_amd.batch")
+
+    def run_batch(g, f0, f1):
+        if f0 >= 8:
+            raise RuntimeError("frame %d" % f0)
+
+    with pytest.raises(RuntimeError):
+        B.StepPipeline(4, 4, 2, 4, run_batch, lambda s: None).run(6)
+    with pytest.raises(ValueError):
+        B.StepPipeline(4, 16, 2, 2, run_batch, lambda s: None)
+
+
+def test_bench_spawns_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment must start N ranks as a child job."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    calls = {}
+
+    def fake_run(cmd, env=None):
+        calls["cmd"], calls["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = calls["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and "127.0.0.1" in cmd
+    assert "torch" not in bench.__dict__        # the parent never imported torch at module level

@@ -30,7 +30,8 @@ def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name):
         m = first_mismatch(what, oh.get(what), got)
         if m:
             problems.append(m)
-        assert hashlib.sha256(got.tobytes()).hexdigest() == GOLD[name]["sha256"][what] or m, what
+        if not m:       # equal to the oracle run here: then equal to the committed hash too (a mismatch is reported once, below)
+            assert hashlib.sha256(got.tobytes()).hexdigest() == GOLD[name]["sha256"][what], what
     assert not problems, "\n".join(problems)
     assert np.array_equal(olab, glab)
     assert hashlib.sha256(glab.tobytes()).hexdigest() == GOLD[name]["labels_sha256"]

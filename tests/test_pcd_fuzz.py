@@ -106,6 +106,10 @@ def test_malformed_files_are_refused(P, tmp_path):
         "bad_sizes": good.replace(b"SIZE 4", b"SIZE 0", 1),
         "no_xyz": good.replace(b" x ", b" q ", 1) if b" x " in good else good.replace(b"FIELDS x", b"FIELDS q", 1),
         "huge_points": good.replace(b"POINTS 50", b"POINTS 4000000000").replace(b"WIDTH 50", b"WIDTH 4000000000"),
+        # header ends at "DATA binary" / "DATA binary_compressed" with no newline and no payload (size underflow)
+        "no_newline_after_data": good[:good.index(b"DATA binary") + 11].replace(b"POINTS 50", b"POINTS 100000").replace(b"WIDTH 50", b"WIDTH 100000"),
+        "no_newline_after_data_compressed": comp[:comp.index(b"DATA binary_compressed") + 22],
+        "rgb_two_bytes": b"VERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 2\nTYPE F F F U\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA binary\n" + bytes(28),
         "garbage": bytes(rng.integers(0, 256, 4096).astype(np.uint8)),
         "lzf_bad_backref": comp[:comp.index(b"DATA binary_compressed\n") + 23] + struct.pack("<II", 8, 5000) + bytes([0xE0, 0xFF, 0xFF, 0, 0, 0, 0, 0]),
     }
