@@ -158,7 +158,8 @@ def main():
             B.gather_label_block(label_blocks[s % n_blocks], dist, gather_list, dst=0)
         gather_stream.synchronize()     # the ring slot is written again by a later step (on libf3ds' own streams)
 
-    pipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, gather_step if dist_on else None)
+    ramp = os.environ.get("F3DS_BENCH_RAMP", "1") != "0"       # development: 0 = equal calls (see plan_batches)
+    pipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, gather_step if dist_on else None, ramp=ramp)
 
     def barrier():
         if dist_on:
@@ -175,6 +176,7 @@ def main():
             t.join()
 
     use_every_context()
+    use_every_context()       # second use: every context's scratch goes to the device-wide high-water marks of the first pass
     barrier()
     pipe.run(args.warmup)
     barrier()
@@ -199,7 +201,7 @@ def main():
         host_frames.extend(torch.from_numpy(f).pin_memory() for f in frames_host)
         host_labels.extend(torch.empty((FPS, npts), dtype=torch.int32).pin_memory() for _ in range(n_blocks))
         mode["host"] = True
-        hpipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, None)
+        hpipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, None, ramp=ramp)
         use_every_context()                                 # contexts allocate their upload buffers once
         barrier()
         th = time.perf_counter()
@@ -279,7 +281,7 @@ def main():
                                        "-v 0.008 -s 0.08 --AL --CVX -t %g, frames resident in HBM" % (FPS, args.width, args.height, npts, prm.threshold),
                            "frames_per_step_per_gpu": FPS, "points_per_step": world * FPS * npts, "frames_timed": world * total_frames,
                            "batch_calls": len(plan), "frames_per_call": round(total_frames / max(1, len(plan)), 1), "concurrent_calls": ngroups, "distinct_frames_per_gpu": FPS,
-                           "setup": "one untimed pass over all contexts (scratch allocation) before the warm-up steps",
+                           "setup": "two untimed passes over all contexts (scratch allocation up to the high-water marks of the 64 frames) before the warm-up steps",
                            "parallelism": ("%d ranks, one per GPU, every rank its own frames" % world) if world > 1 else "1 GPU",
                            "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},

@@ -52,23 +52,50 @@ def gather_label_block(block, dist, bufs=None, dst=0):
     return bufs if rank == dst else None
 
 
-def plan_batches(total_frames, max_batch, groups):
-    """Cut `total_frames` consecutive frames into batch calls of at most `max_batch` frames such that the number of calls is a
-    multiple of `groups` (no host thread idles in the last round) and the calls are as equal as possible.
-    Returns [(first, last+1), ...]."""
+def plan_batches(total_frames, max_batch, groups, ramp=False):
+    """Cut `total_frames` consecutive frames into batch calls of at most `max_batch` frames.  Returns [(first, last+1), ...].
+
+    ramp=False: the number of calls is a multiple of `groups` (no host thread idles in the last round) and the calls are as
+    equal as possible.
+    ramp=True (what bench.py uses): the first `groups` calls grow (max_batch/groups, 2 max_batch/groups, ...) and the last
+    `groups` shrink the same way, equal calls in between.  The host threads then reach the merge stage -- one long
+    dispatch that holds most CUs -- at different times from the first round on, so that one call's wide kernels always
+    have another call's merge loops to overlap with, and they finish together instead of leaving the last call alone on
+    the GPU.  Short runs (the driver's --steps 20) spend most of their time in these two rounds."""
     if total_frames <= 0:
         return []
     max_batch, groups = max(1, max_batch), max(1, groups)
-    calls = -(-total_frames // max_batch)
-    if total_frames >= groups:
-        calls = -(-calls // groups) * groups
-    size, extra = divmod(total_frames, calls)
+    sizes = []
+    if ramp and groups > 1 and total_frames >= 2 * max_batch:
+        up = [max(1, -(-max_batch * (g + 1) // groups)) for g in range(groups)]
+        head, tail = list(up), list(reversed(up))
+        if sum(head) + sum(tail) > total_frames:      # not enough frames for two full ramps: scale both
+            f = total_frames / float(sum(head) + sum(tail))
+            head = [max(1, int(x * f)) for x in head]; tail = [max(1, int(x * f)) for x in tail]
+        mid = total_frames - sum(head) - sum(tail)
+        if mid < 0:
+            return plan_batches(total_frames, max_batch, groups, False)
+        while 0 < mid < max(2, max_batch // groups):  # a remainder too small for a call of its own goes to the big calls
+            for lst, i in ((head, -1), (tail, 0), (head, -2), (tail, 1)):
+                if mid > 0 and lst[i] < max_batch:
+                    lst[i] += 1; mid -= 1
+            if head[-1] >= max_batch and tail[0] >= max_batch and head[-2] >= max_batch and tail[1] >= max_batch:
+                break
+        calls = -(-mid // max_batch) if mid > 0 else 0
+        size, extra = divmod(mid, calls) if calls else (0, 0)
+        sizes = head + [size + (1 if i < extra else 0) for i in range(calls)] + tail
+    else:
+        calls = -(-total_frames // max_batch)
+        if total_frames >= groups:
+            calls = -(-calls // groups) * groups
+        size, extra = divmod(total_frames, calls)
+        sizes = [size + (1 if i < extra else 0) for i in range(calls)]
     out, f = [], 0
-    for i in range(calls):
-        k = size + (1 if i < extra else 0)
-        if k:
+    for k in sizes:
+        if k > 0:
             out.append((f, f + k))
             f += k
+    assert f == total_frames
     return out
 
 
@@ -79,8 +106,8 @@ class StepPipeline:
     (the label gather of that step).  A step's label block is one of `n_blocks` ring slots: a batch that would write
     into the slot of a step not gathered yet waits.  Exceptions of any thread are re-raised by run()."""
 
-    def __init__(self, frames_per_step, max_batch, groups, n_blocks, run_batch, on_step=None):
-        self.fps, self.max_batch, self.groups, self.n_blocks = frames_per_step, max_batch, groups, n_blocks
+    def __init__(self, frames_per_step, max_batch, groups, n_blocks, run_batch, on_step=None, ramp=False):
+        self.fps, self.max_batch, self.groups, self.n_blocks, self.ramp = frames_per_step, max_batch, groups, n_blocks, ramp
         self.run_batch, self.on_step = run_batch, on_step
         if on_step is not None and n_blocks * frames_per_step < max_batch + frames_per_step:
             raise ValueError("label ring too small for one batch call")
@@ -90,7 +117,7 @@ class StepPipeline:
 
     def run(self, n_steps):
         total = n_steps * self.fps
-        plan = plan_batches(total, self.max_batch, self.groups)
+        plan = plan_batches(total, self.max_batch, self.groups, self.ramp)
         cv = threading.Condition()
         state = {"next": 0, "done": [0] * n_steps, "gathered": 0, "err": None}
 

@@ -20,6 +20,7 @@
 // reference order inside each reduction.  Built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -120,6 +121,7 @@ struct f3ds_ctx {
     uint64_t *eks = nullptr;                             // sorted edge keys
     f3ds_result res;
     bool merge_in_lds = false;
+    int merge_kind = 0;                // which merge kernel the last cluster stage ran (MergeKind)
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
     int refined_itr = -1;              // >= 0: the r_* buffers hold the state after that many refinement iterations of this frame
@@ -150,19 +152,40 @@ bool referenced_by_pending_calls(const f3ds_ctx* c, const Buf& b) {
     }
     return false;
 }
+// Scratch is grow-only per context, and sized by the largest frame ANY context of the device has seen: g_scratch_hwm holds,
+// per buffer slot, the largest request so far.  A context that has to grow a buffer -- or meets a request below the mark
+// while nothing recorded refers to the buffer -- goes straight to the mark (if that is within 4x of its own request), so that
+// a pool of contexts fed with frames of varying size stops allocating after every context has been used twice (hipFree waits for the whole device: a
+// regrow in steady state stalls every batch in flight).
+std::atomic<size_t> g_scratch_hwm[16][160];
+std::atomic<unsigned long long> g_scratch_allocs{0};      // hipMalloc calls for scratch so far (F3DS_HOST_PROF prints it per batch)
 template <class T>
 int ensure(f3ds_ctx* c, Buf& b, size_t count, T** out) {
     size_t bytes = count * sizeof(T);
     if (bytes < 256) bytes = 256;
-    if (b.cap < bytes) {
-        if (b.p && !c->cmds.empty() && referenced_by_pending_calls(c, b)) {
+    size_t target = bytes;
+    const ptrdiff_t slot = &b - &c->pts;
+    if (slot >= 0 && slot < 160) {
+        std::atomic<size_t>& hwm = g_scratch_hwm[c->device & 15][slot];
+        size_t seen = hwm.load(std::memory_order_relaxed);
+        while (seen < bytes && !hwm.compare_exchange_weak(seen, bytes, std::memory_order_relaxed)) {}
+        if (seen > target && seen <= 4 * bytes) target = seen;      // (a frame of another scale altogether does not size this one)
+    }
+    if (b.cap < target) {
+        const bool pinned = b.p && !c->cmds.empty() && referenced_by_pending_calls(c, b);
+        if (pinned && b.cap < bytes) {
             fprintf(stderr, "f3ds: internal error: regrowing a buffer that a recorded kernel call refers to\n");
             return F3DS_ERR_LOGIC;
         }
-        if (b.p) { HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-        size_t want = bytes + bytes / 4 + 64;
-        HIPCHECK(hipMalloc(&b.p, want));
-        b.cap = want;
+        if (!pinned) {
+            g_scratch_allocs.fetch_add(1, std::memory_order_relaxed);
+            static const bool trace = getenv("F3DS_TRACE_ALLOC") != nullptr;
+            if (trace && b.p) fprintf(stderr, "f3ds: regrow slot %td: cap %zu, request %zu, mark %zu, pending calls %zu\n", slot, b.cap, bytes, target, c->cmds.size());
+            if (b.p) { HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+            size_t want = target + target / 4 + 64;
+            HIPCHECK(hipMalloc(&b.p, want));
+            b.cap = want;
+        }
     }
     *out = reinterpret_cast<T*>(b.p);
     return F3DS_OK;
@@ -540,8 +563,51 @@ bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl, bool keys_global = fa
     if (xl->caprows > 2048u) xl->caprows = 2048u;
     return ok;
 }
+// second-generation merge kernel d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
+bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, bool keys_lds, uint32_t budget, MergeLds* xl) {
+    memset(xl, 0, sizeof *xl);
+    xl->Ecap = (E + 63u) & ~63u; if (!xl->Ecap) xl->Ecap = 64u;
+    const uint32_t T = (uint32_t)nw * 64u;
+    const uint32_t fixed = xl->Ecap * (keys_lds ? 8u : 4u) + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
+    xl->stage_off = (fixed + 15u) & ~15u;
+    xl->keys_in_lds = keys_lds ? 1 : 0;
+    xl->caprows = 2u * T;
+    xl->G = xl->Ecap / 64u;
+    return xl->stage_off + 2u * T * 52u <= budget && S0 <= 65534u;
+}
+inline uint32_t merge_cw_lds_bytes(const MergeLds& xl, int nw) { return xl.stage_off + 2u * (uint32_t)nw * 64u * 52u; }
+enum MergeKind { MK_GLOBAL = 0, MK_LDS = 1, MK_LDS_BIG = 2, MK_CW2_KL = 3, MK_CW2_KG = 4, MK_CW8_KL = 5, MK_CW8_KG = 6 };
+// Which merge kernel a batch runs (one dispatch for all its frames).  Many frames: the compact 2-wave workgroup (the
+// merge loops then leave most of every CU to the other batches' kernels); few frames: the 8-wave one (a lone frame's
+// latency).  Development switches: F3DS_MERGE_KERNEL=old|cw, F3DS_MERGE_NW=2|8, F3DS_MERGE_KEYS=lds|global,
+// F3DS_MERGE_COMPACT_MIN=<frames>, and the round-1 F3DS_FORCE_GLOBAL_MERGE / F3DS_FORCE_BIG_MERGE.
+int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
+    if (force_global || getenv("F3DS_FORCE_GLOBAL_MERGE")) return MK_GLOBAL;
+    const char* kern = getenv("F3DS_MERGE_KERNEL");
+    if ((kern && !strcmp(kern, "old")) || getenv("F3DS_FORCE_BIG_MERGE")) {
+        bool all_lds = true, keys_global = false;
+        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_fits_lds(c->E, c->S0, &t)) all_lds = false; else if (!t.keys_in_lds) keys_global = true; }
+        return !all_lds ? MK_GLOBAL : (keys_global ? MK_LDS_BIG : MK_LDS);
+    }
+    const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
+    const size_t compact_min = e_min ? (size_t)atol(e_min) : 16u;
+    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : 8) : (fr.size() >= compact_min ? 2 : 8);
+    // compact: keys stay in LDS while the workgroup keeps to ~half of a CU's 160 KB (something else fits beside it)
+    const uint32_t full = 160u * 1024u - 2048u;
+    const uint32_t want = nw == 2 ? 96u * 1024u : full;
+    bool kl = !(e_keys && !strcmp(e_keys, "global")), ok = true;
+    for (int pass = 0; pass < 2; ++pass) {
+        ok = true;
+        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, kl, (kl && !(e_keys && !strcmp(e_keys, "lds"))) ? want : full, &t)) ok = false; }
+        if (ok || !kl) break;
+        kl = false;
+    }
+    if (!ok) return MK_GLOBAL;
+    return nw == 2 ? (kl ? MK_CW2_KL : MK_CW2_KG) : (kl ? MK_CW8_KL : MK_CW8_KG);
+}
 // stage 4c: Clustering::cluster(threshold) up to the merge loop: working copies, deltas, lambda / cdf, weights
-int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds, bool keys_global) {
+int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
+    const bool use_lds = kind != MK_GLOBAL, keys_global = kind == MK_LDS_BIG;
     const uint32_t S0 = c->S0, E = c->E;
     // main(): set_merging / set_lambda / set_bins_num (src/supervoxel_clustering.cpp:415-423)
     float lambda = 0.5f; int bins = 500;
@@ -570,13 +636,14 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds, bool ke
     rec_copy(c, m.ea, c->ea0.p, (size_t)E * 4);
     rec_copy(c, m.eb, c->eb0.p, (size_t)E * 4);
     MergeLds xl;
-    merge_fits_lds(E, S0, &xl, keys_global);
+    if (kind >= MK_CW2_KL) merge_cw_layout(E, S0, kind <= MK_CW2_KG ? 2 : 8, kind == MK_CW2_KL || kind == MK_CW8_KL, 0xFFFFFFFFu, &xl);
+    else merge_fits_lds(E, S0, &xl, keys_global);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u) * c->pool_mult;
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
     ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
     xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);
-    c->merge_in_lds = use_lds;
+    c->merge_in_lds = use_lds; c->merge_kind = kind;
     rec<d_region_reset>(c, grid_for(S0 + 1, 256), 0u, S0, (const uint32_t*)c->hcount.p, m.rhead, m.rtail, m.lnext, m.parent, m.markA, m.markB, xl.pool, xl.rstart, xl.rnleaf, xl.rcap, (const uint32_t*)c->loff.p);
     m.mp.color_metric = prm->color_metric; m.mp.geom_metric = prm->geom_metric; m.mp.merging = prm->merging; m.mp.lambda = lambda; m.mp.bins = bins;
     uint64_t *sk0 = nullptr, *sk1 = nullptr; uint32_t *sv0 = nullptr, *sv1 = nullptr;
@@ -604,9 +671,15 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, bool use_lds, bool ke
 }
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
-    if (c->merge_in_lds && c->mlds.keys_in_lds) rec<d_merge_lds>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds);
-    else if (c->merge_in_lds) rec<d_merge_lds_big>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds);
-    else rec<d_merge>(c, 1u, 0u, c->mdev);
+    switch (c->merge_kind) {
+        case MK_LDS: rec<d_merge_lds>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds); break;
+        case MK_LDS_BIG: rec<d_merge_lds_big>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds); break;
+        case MK_CW2_KL: rec<d_merge_cw_t<2, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 2), c->mdev, c->mlds); break;
+        case MK_CW2_KG: rec<d_merge_cw_t<2, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 2), c->mdev, c->mlds); break;
+        case MK_CW8_KL: rec<d_merge_cw_t<8, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 8), c->mdev, c->mlds); break;
+        case MK_CW8_KG: rec<d_merge_cw_t<8, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 8), c->mdev, c->mlds); break;
+        default: rec<d_merge>(c, 1u, 0u, c->mdev);
+    }
     return F3DS_OK;
 }
 // stage 6: region ids (ascending surviving label) and per-point labels
@@ -666,10 +739,9 @@ void stage_mark(Batch& b, int i) { (void)hipEventRecord(b.owner->ev[i], b.st); }
 
 // cluster stage for the live frames (also the whole of f3ds_recluster)
 int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, const std::vector<int>& index_of, int labels_on_device, bool force_global = false) {
-    bool all_lds = !force_global;
-    bool keys_global = false;        // one kernel for the whole batch: if any frame needs the 4-bytes-per-edge layout, all use it
-    for (f3ds_ctx* c : b.fr) { MergeLds t; if (!merge_fits_lds(c->E, c->S0, &t)) all_lds = false; else if (!t.keys_in_lds) keys_global = true; }
-    int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, all_lds, keys_global); });
+    const int kind = choose_merge_kind(b.fr, force_global);      // one kernel for the whole batch
+    const bool all_lds = kind != MK_GLOBAL;
+    int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, kind); });
     if (rc || (rc = flush(b))) return rc;
     stage_mark(b, 5);
     if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
@@ -693,6 +765,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
             if (c->h_dc->ev_overflow == 2 && c->pool_mult < 64u) { c->pool_mult *= 4u; again = true; }
         }
         if (again) {
+            if (getenv("F3DS_TRACE_ERR")) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with more history / leaf-pool room\n", b.fr.size());
             for (f3ds_ctx* c : b.fr) {
                 c->h_dc->error = 0; c->h_dc->ev_overflow = 0;
                 HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->ev_overflow, 0, sizeof(int), b.st));
@@ -706,6 +779,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         bool again = false;
         for (f3ds_ctx* c : b.fr) if (c->h_dc->error == F3DS_ERR_UNSUPPORTED) again = true;
         if (again) {
+            if (getenv("F3DS_TRACE_ERR")) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with the global-memory kernel\n", b.fr.size());
             for (f3ds_ctx* c : b.fr) { c->h_dc->error = 0; HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); }
             return run_cluster(b, prm, labels_of, index_of, labels_on_device, true);
         }
@@ -893,7 +967,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     // device time of each stage of the whole batch (HIP events on the batch's stream)
     for (int k = 0; k < 7; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[k], b.owner->ev[k + 1]) == hipSuccess) stage[k] = ms; }
     const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("F3DS_HOST_PROF")) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch);
+    if (getenv("F3DS_HOST_PROF")) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic; stages %.0f %.0f %.0f %.0f %.0f %.0f %.0f ms; %llu scratch allocations so far\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch, stage[0], stage[1], stage[2], stage[3], stage[4], stage[5], stage[6], g_scratch_allocs.load());
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
         for (int k = 0; k < 8; ++k) c->res.ms_stage[k] = stage[k];

@@ -113,7 +113,15 @@ def test_plan_batches_covers_every_frame_once():
         if plan:
             sizes = [b - a for a, b in plan]
             assert max(sizes) - min(sizes) <= 1
-    assert len(B.plan_batches(1280, 192, 4)) == 8           # the driver's --steps 20: 8 calls of 160 frames
+    assert len(B.plan_batches(1280, 192, 4)) == 8           # the driver's --steps 20 without the ramps: 8 calls of 160 frames
+    # with ramps: growing first round, shrinking last round, every frame once, no call above the limit, no crumbs
+    for total, mb, g in [(1280, 192, 4), (3072, 192, 4), (384, 192, 4), (768, 192, 4), (64, 192, 4), (400, 192, 4), (5, 2, 3), (100000, 192, 4), (385, 192, 1)]:
+        plan = B.plan_batches(total, mb, g, ramp=True)
+        sizes = [b - a for a, b in plan]
+        assert [f for a, b in plan for f in range(a, b)] == list(range(total)) and max(sizes) <= mb
+        if total >= 2 * mb and g > 1 and mb >= 8:
+            assert sizes[:g] == sorted(sizes[:g]) and sizes[-g:] == sorted(sizes[-g:], reverse=True) and min(sizes) >= min(sizes[0], sizes[-1])
+    assert [b - a for a, b in B.plan_batches(1280, 192, 4, ramp=True)] == [48, 96, 144, 192, 160, 160, 192, 144, 96, 48]
 
 
 def _pipeline_worker(rank, world, port, n_steps, q):

@@ -305,6 +305,41 @@ def test_merge_kernel_with_keys_in_global_memory(P):
         assert got[n]["labels"] == gold[n]["labels_sha256"] and got[n]["MERGES"] == gold[n]["sha256"]["MERGES"], n
 
 
+MERGE_VARIANTS = [dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="global"),
+                  dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="global"),
+                  dict(F3DS_MERGE_KERNEL="old"), dict(F3DS_MERGE_KERNEL="old", F3DS_FORCE_BIG_MERGE="1")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", MERGE_VARIANTS, ids=lambda v: "-".join("%s" % x for x in v.values()))
+def test_every_merge_kernel_layout_gives_the_oracle_merges(P, oracle, monkeypatch, variant):
+    """The merge loop exists as d_merge_cw_t<2 | 8 waves, keys in LDS | global> (chosen by batch size and adjacency count),
+    the round-1 d_merge_lds / d_merge_lds_big and the all-global d_merge: each forced here (switches are read per call)
+    on golden cases and on the 1M-point frame (regions of > 30 000 voxels and hundreds of leaves: multi-chunk staging)."""
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
+    ctx = P.Context(0)
+    for n in ["rgbd_320x240_ghosts", "rgbd_160x120_equalization", "fixture_launch_flags", "fused_200k_nan_lambda", "rgbd_320x240_large_supervoxels",
+              "rgbd_160x120_threshold_1", "rgbd_160x120_rgb_metric"]:
+        lab = ctx.segment(case_points(P, n), case_params(P, n))
+        assert hashlib.sha256(lab.tobytes()).hexdigest() == gold[n]["labels_sha256"], n
+        assert hashlib.sha256(ctx.debug("MERGES").tobytes()).hexdigest() == gold[n]["sha256"]["MERGES"], n
+    # voxel cloud order (leaf arrays of the merged regions) and region records against the oracle run here
+    pts = case_points(P, "rgbd_320x240_ghosts"); prm = case_params(P, "rgbd_320x240_ghosts")
+    rc, olab, ores, oh = oracle.segment(pts, prm)
+    assert np.array_equal(ctx.segment(pts, prm), olab)
+    ox, ol, _ = oh.voxel_cloud(); gx, gl, _ = ctx.voxel_cloud()
+    assert np.array_equal(ox.view(np.uint32), gx.view(np.uint32)) and np.array_equal(ol, gl)
+    for seed in (1000, 1061):
+        e = big["config5_seed%d" % seed]
+        lab = ctx.segment(P.synth_frame(*e["synth"]), P.launch_params(**e["params"]))
+        assert hashlib.sha256(lab.tobytes()).hexdigest() == e["labels_sha256"], seed
+        assert hashlib.sha256(ctx.debug("MERGES").tobytes()).hexdigest() == e["sha256"]["MERGES"], seed
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_vccs_getters_match_oracle(P, oracle, gpu_ctx):
     """getVoxelCentroidCloud / supervoxel_clusters / makeSupervoxelNormalCloud / getSupervoxelAdjacency
