@@ -576,7 +576,9 @@ bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, bool keys_lds, uint32_t bu
     return xl->stage_off + 2u * T * 52u <= budget && S0 <= 65534u;
 }
 inline uint32_t merge_cw_lds_bytes(const MergeLds& xl, int nw) { return xl.stage_off + 2u * (uint32_t)nw * 64u * 52u; }
-enum MergeKind { MK_GLOBAL = 0, MK_LDS = 1, MK_LDS_BIG = 2, MK_CW2_KL = 3, MK_CW2_KG = 4, MK_CW8_KL = 5, MK_CW8_KG = 6 };
+enum MergeKind { MK_GLOBAL = 0, MK_LDS = 1, MK_LDS_BIG = 2, MK_CW2_KL = 3, MK_CW2_KG = 4, MK_CW4_KL = 5, MK_CW4_KG = 6, MK_CW8_KL = 7, MK_CW8_KG = 8 };
+inline int mk_waves(int kind) { return kind <= MK_CW2_KG ? 2 : (kind <= MK_CW4_KG ? 4 : 8); }
+inline bool mk_keys_lds(int kind) { return kind == MK_CW2_KL || kind == MK_CW4_KL || kind == MK_CW8_KL; }
 // Which merge kernel a batch runs (one dispatch for all its frames).  Many frames: the compact 2-wave workgroup (the
 // merge loops then leave most of every CU to the other batches' kernels); few frames: the 8-wave one (a lone frame's
 // latency).  Development switches: F3DS_MERGE_KERNEL=old|cw, F3DS_MERGE_NW=2|8, F3DS_MERGE_KEYS=lds|global,
@@ -591,7 +593,7 @@ int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
     }
     const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
     const size_t compact_min = e_min ? (size_t)atol(e_min) : 16u;
-    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : 8) : (fr.size() >= compact_min ? 2 : 8);
+    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : (atoi(e_nw) == 4 ? 4 : 8)) : (fr.size() >= compact_min ? 2 : 8);
     // compact: keys stay in LDS while the workgroup keeps to ~half of a CU's 160 KB (something else fits beside it)
     const uint32_t full = 160u * 1024u - 2048u;
     const uint32_t want = nw == 2 ? 96u * 1024u : full;
@@ -603,7 +605,7 @@ int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
         kl = false;
     }
     if (!ok) return MK_GLOBAL;
-    return nw == 2 ? (kl ? MK_CW2_KL : MK_CW2_KG) : (kl ? MK_CW8_KL : MK_CW8_KG);
+    return nw == 2 ? (kl ? MK_CW2_KL : MK_CW2_KG) : (nw == 4 ? (kl ? MK_CW4_KL : MK_CW4_KG) : (kl ? MK_CW8_KL : MK_CW8_KG));
 }
 // stage 4c: Clustering::cluster(threshold) up to the merge loop: working copies, deltas, lambda / cdf, weights
 int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
@@ -636,7 +638,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     rec_copy(c, m.ea, c->ea0.p, (size_t)E * 4);
     rec_copy(c, m.eb, c->eb0.p, (size_t)E * 4);
     MergeLds xl;
-    if (kind >= MK_CW2_KL) merge_cw_layout(E, S0, kind <= MK_CW2_KG ? 2 : 8, kind == MK_CW2_KL || kind == MK_CW8_KL, 0xFFFFFFFFu, &xl);
+    if (kind >= MK_CW2_KL) merge_cw_layout(E, S0, mk_waves(kind), mk_keys_lds(kind), 0xFFFFFFFFu, &xl);
     else merge_fits_lds(E, S0, &xl, keys_global);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u) * c->pool_mult;
@@ -676,6 +678,8 @@ int seg_merge(f3ds_ctx* c) {
         case MK_LDS_BIG: rec<d_merge_lds_big>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds); break;
         case MK_CW2_KL: rec<d_merge_cw_t<2, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 2), c->mdev, c->mlds); break;
         case MK_CW2_KG: rec<d_merge_cw_t<2, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 2), c->mdev, c->mlds); break;
+        case MK_CW4_KL: rec<d_merge_cw_t<4, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 4), c->mdev, c->mlds); break;
+        case MK_CW4_KG: rec<d_merge_cw_t<4, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 4), c->mdev, c->mlds); break;
         case MK_CW8_KL: rec<d_merge_cw_t<8, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 8), c->mdev, c->mlds); break;
         case MK_CW8_KG: rec<d_merge_cw_t<8, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 8), c->mdev, c->mlds); break;
         default: rec<d_merge>(c, 1u, 0u, c->mdev);

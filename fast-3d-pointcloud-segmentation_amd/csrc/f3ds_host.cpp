@@ -287,17 +287,101 @@ inline uint64_t splitmix(uint64_t& s) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
     return z ^ (z >> 31);
 }
+// The generator's own logarithm and cosine: round 1's series (separate multiply and add), frozen here so that the synthetic
+// frames of BASELINE.md stay byte-identical while csrc/f3ds_math.h (the arithmetic of the path) is free to change.
+inline double gen_estrin8(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double z) {
+    const double z2 = z * z, z4 = z2 * z2;
+    const double a0 = c0 + c1 * z, a1 = c2 + c3 * z, a2 = c4 + c5 * z, a3 = c6 + c7 * z;
+    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2;
+    return b0 + b1 * z4;
+}
+
+inline double gen_estrin16(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double c8, double c9,
+                          double c10, double c11, double c12, double c13, double c14, double c15, double z) {
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double a0 = c0 + c1 * z, a1 = c2 + c3 * z, a2 = c4 + c5 * z, a3 = c6 + c7 * z;
+    const double a4 = c8 + c9 * z, a5 = c10 + c11 * z, a6 = c12 + c13 * z, a7 = c14 + c15 * z;
+    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2, b2 = a4 + a5 * z2, b3 = a6 + a7 * z2;
+    const double d0 = b0 + b1 * z4, d1 = b2 + b3 * z4;
+    return d0 + d1 * z8;
+}
+
+inline double gen_log(double x) {
+    if (f3ds::m_isnan(x)) return x;
+    if (x < 0.0) return f3ds::m_nan();
+    if (x == 0.0) return -f3ds::m_inf();
+    if (f3ds::m_isinf(x)) return x;
+    int e = 0;
+    if (x < 0x1p-1022) { x = x * 0x1p54; e = -54; }   // subnormal
+    uint64_t u = f3ds::m_bits(x);
+    e += (int)(u >> 52) - 1023;
+    double m = f3ds::m_from_bits((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);   // [1,2)
+    if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }                       // [0.7071,1.4142]
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    // 2*atanh(s) = 2s * (1 + z/3 + z^2/5 + ...),  z <= 0.0295: 16 terms of 1/(2k+3)
+    const double p = gen_estrin16(1.0 / 3.0, 1.0 / 5.0, 1.0 / 7.0, 1.0 / 9.0, 1.0 / 11.0, 1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0,
+                                1.0 / 23.0, 1.0 / 25.0, 1.0 / 27.0, 1.0 / 29.0, 1.0 / 31.0, 1.0 / 33.0, z);
+    const double LN2_HI = 0x1.62e4200000000p-1;
+    const double LN2_LO = 0x1.fdf473de6af28p-22;
+    double ed = (double)e;
+    double two_s = 2.0 * s;
+    double r = ed * LN2_LO + two_s * (z * p);
+    r = r + two_s;
+    r = r + ed * LN2_HI;
+    return r;
+}
+
+inline double gen_sin_kernel(double r) {
+    const double z = r * r;
+    const double p = gen_estrin8(-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0, 1.0 / 6227020800.0,
+                               -1.0 / 1307674368000.0, 1.0 / 355687428096000.0, z);
+    return r + r * (z * p);
+}
+
+inline double gen_cos_kernel(double r) {
+    const double z = r * r;
+    const double p = gen_estrin16(-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0, -1.0 / 87178291200.0,
+                                1.0 / 20922789888000.0, -1.0 / 6402373705728000.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, z);
+    return 1.0 + z * p;
+}
+
+inline int gen_rem_pio2(double x, double* r) {
+    const double TWO_OVER_PI = 0.6366197723675814;
+    const double PIO2_1 = 0x1.921fb54400000p+0;      // 33 bits
+    const double PIO2_2 = 0x1.0b4611a600000p-34;     // next 33 bits
+    const double PIO2_3 = 0x1.3198a2e037073p-69;
+    double t = x * TWO_OVER_PI;
+    double nd = (double)(long long)(t + (t < 0.0 ? -0.5 : 0.5));
+    *r = ((x - nd * PIO2_1) - nd * PIO2_2) - nd * PIO2_3;
+    return (int)((long long)nd & 3);
+}
+
+inline double gen_cos(double x) {
+    if (f3ds::m_isnan(x) || f3ds::m_isinf(x)) return f3ds::m_nan();
+    if (f3ds::m_abs(x) <= 0.7853981633974483) return gen_cos_kernel(x);
+    if (f3ds::m_abs(x) > 1.0e15) return f3ds::m_nan();
+    double r; int q = gen_rem_pio2(x, &r);
+    switch (q) {
+        case 0: return gen_cos_kernel(r);
+        case 1: return -gen_sin_kernel(r);
+        case 2: return -gen_cos_kernel(r);
+        default: return gen_sin_kernel(r);
+    }
+}
+
 struct Rng {
     uint64_t s;
     explicit Rng(uint64_t seed) : s(seed) {}
     double uni() { return (double)(splitmix(s) >> 11) * (1.0 / 9007199254740992.0); }
     double uni(double a, double b) { return a + (b - a) * uni(); }
-    double gauss() {   // Box-Muller on the shared math (platform independent)
+    double gauss() {   // Box-Muller on IEEE basic operations (platform independent)
         double u1 = uni(), u2 = uni();
         if (u1 < 1e-300) u1 = 1e-300;
-        double r2 = -2.0 * f3ds::m_log(u1);
+        double r2 = -2.0 * gen_log(u1);
         double r = r2 > 0 ? __builtin_sqrt(r2) : 0.0;
-        return r * f3ds::m_cos(6.283185307179586 * u2);
+        return r * gen_cos(6.283185307179586 * u2);
     }
 };
 struct Box { double lo[3], hi[3]; uint8_t col[3]; };

@@ -4,9 +4,10 @@
 // generated (single-camera transform) and uses atan2/cos/sin/exp inside the merge
 // distance.  libm (host) and ocml (device) do not return the same last bit for those,
 // and one flipped bit can move a point to the neighbouring voxel or reorder two merges.
-// Every function below uses only + - * / sqrt, integer bit moves and comparisons, so
-// the same source gives the same bits from g++ (x86-64, SSE2) and from hipcc (gfx950),
-// provided both are compiled with -ffp-contract=off (the build scripts do that).
+// Every function below uses only + - * / sqrt fma, integer bit moves and comparisons, so
+// the same source gives the same bits from g++ (x86-64) and from hipcc (gfx950),
+// provided both are compiled with -ffp-contract=off (the build scripts do that; the host
+// builds add -mfma so that __builtin_fma is the instruction, glibc's fma() gives the same bits).
 //
 // Replaces, at the reference's call sites:
 //   std::log(float)              PCL SupervoxelClustering::transformFunction
@@ -52,43 +53,58 @@ F3DS_HD bool m_isfinitef(float x) { return (m_bitsf(x) & 0x7f800000u) != 0x7f800
 // 2^k as a double for -1022 <= k <= 1023
 F3DS_HD double m_pow2(int k) { return m_from_bits((uint64_t)(k + 1023) << 52); }
 
+// Fused multiply-add is an IEEE-754 basic operation with one rounding: v_fma_f64 on the device, vfmadd (or glibc's exact
+// fma) on the host give the same bits.  Everything below is written with explicit fma -- never contracted by the compiler
+// (-ffp-contract=off) -- because on the GPU these functions sit on the serial path of the merge loop and a wave issues
+// one f64 instruction every ~4.8 cycles whatever the number of active lanes (tools/ubench): instruction count is latency.
+// Round 1's versions (separate multiply and add, 16-term series, 64-bit integer conversions) cost 500-1100 cycles each.
+F3DS_HD double m_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// Polynomials are evaluated with Estrin's scheme (independent sub-sums combined with z^2, z^4,
-// z^8) rather than Horner's: on the GPU a dependent f64 operation costs ~14-16 cycles while an
-// independent one issues every 4, and these functions sit on the serial path of the merge loop.
-// The evaluation order below is part of the bit-exact host/device contract.
+// Polynomials are evaluated with Estrin's scheme (independent sub-sums combined with z^2, z^4, z^8).  The evaluation
+// order below is part of the bit-exact host/device contract.
 F3DS_HD double m_estrin8(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double z) {
     const double z2 = z * z, z4 = z2 * z2;
-    const double a0 = c0 + c1 * z, a1 = c2 + c3 * z, a2 = c4 + c5 * z, a3 = c6 + c7 * z;
-    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2;
-    return b0 + b1 * z4;
+    const double a0 = m_fma(c1, z, c0), a1 = m_fma(c3, z, c2), a2 = m_fma(c5, z, c4), a3 = m_fma(c7, z, c6);
+    const double b0 = m_fma(a1, z2, a0), b1 = m_fma(a3, z2, a2);
+    return m_fma(b1, z4, b0);
 }
-F3DS_HD double m_estrin16(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double c8, double c9,
-                          double c10, double c11, double c12, double c13, double c14, double c15, double z) {
+F3DS_HD double m_estrin12(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double c8, double c9,
+                          double c10, double c11, double z) {
     const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
-    const double a0 = c0 + c1 * z, a1 = c2 + c3 * z, a2 = c4 + c5 * z, a3 = c6 + c7 * z;
-    const double a4 = c8 + c9 * z, a5 = c10 + c11 * z, a6 = c12 + c13 * z, a7 = c14 + c15 * z;
-    const double b0 = a0 + a1 * z2, b1 = a2 + a3 * z2, b2 = a4 + a5 * z2, b3 = a6 + a7 * z2;
-    const double d0 = b0 + b1 * z4, d1 = b2 + b3 * z4;
-    return d0 + d1 * z8;
+    const double a0 = m_fma(c1, z, c0), a1 = m_fma(c3, z, c2), a2 = m_fma(c5, z, c4), a3 = m_fma(c7, z, c6), a4 = m_fma(c9, z, c8), a5 = m_fma(c11, z, c10);
+    const double b0 = m_fma(a1, z2, a0), b1 = m_fma(a3, z2, a2), b2 = m_fma(a5, z2, a4);
+    return m_fma(b2, z8, m_fma(b1, z4, b0));
+}
+F3DS_HD double m_estrin14(double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7, double c8, double c9,
+                          double c10, double c11, double c12, double c13, double z) {
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double a0 = m_fma(c1, z, c0), a1 = m_fma(c3, z, c2), a2 = m_fma(c5, z, c4), a3 = m_fma(c7, z, c6);
+    const double a4 = m_fma(c9, z, c8), a5 = m_fma(c11, z, c10), a6 = m_fma(c13, z, c12);
+    const double b0 = m_fma(a1, z2, a0), b1 = m_fma(a3, z2, a2), b2 = m_fma(a5, z2, a4);
+    const double d0 = m_fma(b1, z4, b0), d1 = m_fma(a6, z4, b2);
+    return m_fma(d1, z8, d0);
+}
+// round to nearest integer (ties to even) for |t| < 2^51 without a 64-bit integer conversion; *q = the integer's low bits
+F3DS_HD double m_rint_small(double t, int* q) {
+    const double MAGIC = 0x1.8p52;
+    const double s = t + MAGIC;
+    *q = (int)(uint32_t)m_bits(s);
+    return s - MAGIC;
 }
 
 // ---- exp -------------------------------------------------------------------------------
 F3DS_HD double m_exp(double x) {
-    if (m_isnan(x)) return x;
-    if (x > 709.782712893384) return m_inf();
+    if (!(x <= 709.782712893384)) return x != x ? x : m_inf();      // NaN or overflow
     if (x < -745.2) return 0.0;
     const double INV_LN2 = 1.4426950408889634;
-    const double LN2_HI = 0x1.62e4200000000p-1;   // 20 significant bits: k*LN2_HI is exact
-    const double LN2_LO = 0x1.fdf473de6af28p-22;
-    double t = x * INV_LN2;
-    int k = (int)(t + (t < 0.0 ? -0.5 : 0.5));
-    double kd = (double)k;
-    double r = (x - kd * LN2_HI) - kd * LN2_LO;    // |r| <= ~0.3466
-    // Taylor series, degree 15 (r^16/16! < 1e-20)
-    const double p = m_estrin16(1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
-                                1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
-                                1.0 / 1307674368000.0, r);
+    const double LN2_HI = 0x1.62e42fefa39efp-1;
+    const double LN2_LO = 0x1.abc9e3b39803fp-56;
+    int k;
+    const double kd = m_rint_small(x * INV_LN2, &k);
+    const double r = m_fma(-kd, LN2_LO, m_fma(-kd, LN2_HI, x));    // |r| <= ~0.3466
+    // Taylor series, degree 13 (r^14/14! < 5e-18)
+    const double p = m_estrin14(1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0,
+                                1.0 / 3628800.0, 1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0, r);
     if (k > 1000) return (p * m_pow2(1000)) * m_pow2(k - 1000);
     if (k < -1000) return (p * m_pow2(-1000)) * m_pow2(k + 1000);
     return p * m_pow2(k);
@@ -96,9 +112,7 @@ F3DS_HD double m_exp(double x) {
 
 // ---- log -------------------------------------------------------------------------------
 F3DS_HD double m_log(double x) {
-    if (m_isnan(x)) return x;
-    if (x < 0.0) return m_nan();
-    if (x == 0.0) return -m_inf();
+    if (!(x > 0.0)) return x == 0.0 ? -m_inf() : m_nan();           // 0, negative, NaN
     if (m_isinf(x)) return x;
     int e = 0;
     if (x < 0x1p-1022) { x = x * 0x1p54; e = -54; }   // subnormal
@@ -106,105 +120,97 @@ F3DS_HD double m_log(double x) {
     e += (int)(u >> 52) - 1023;
     double m = m_from_bits((u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL);   // [1,2)
     if (m > 1.4142135623730951) { m = m * 0.5; e = e + 1; }                       // [0.7071,1.4142]
-    double f = m - 1.0;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    // 2*atanh(s) = 2s * (1 + z/3 + z^2/5 + ...),  z <= 0.0295: 16 terms of 1/(2k+3)
-    const double p = m_estrin16(1.0 / 3.0, 1.0 / 5.0, 1.0 / 7.0, 1.0 / 9.0, 1.0 / 11.0, 1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0,
-                                1.0 / 23.0, 1.0 / 25.0, 1.0 / 27.0, 1.0 / 29.0, 1.0 / 31.0, 1.0 / 33.0, z);
-    const double LN2_HI = 0x1.62e4200000000p-1;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    // 2*atanh(s) = 2s * (1 + z/3 + z^2/5 + ...),  z <= 0.0295: 12 terms of 1/(2k+3) (z^12/27 < 2e-20)
+    const double p = m_estrin12(1.0 / 3.0, 1.0 / 5.0, 1.0 / 7.0, 1.0 / 9.0, 1.0 / 11.0, 1.0 / 13.0, 1.0 / 15.0, 1.0 / 17.0, 1.0 / 19.0, 1.0 / 21.0,
+                                1.0 / 23.0, 1.0 / 25.0, z);
+    const double LN2_HI = 0x1.62e4200000000p-1;      // 20 significant bits: ed * LN2_HI is exact
     const double LN2_LO = 0x1.fdf473de6af28p-22;
-    double ed = (double)e;
-    double two_s = 2.0 * s;
-    double r = ed * LN2_LO + two_s * (z * p);
+    const double ed = (double)e;
+    const double two_s = 2.0 * s;
+    double r = m_fma(two_s, z * p, ed * LN2_LO);
     r = r + two_s;
-    r = r + ed * LN2_HI;
-    return r;
+    return m_fma(ed, LN2_HI, r);
 }
 
 // ---- sin / cos -------------------------------------------------------------------------
-// Cody-Waite reduction by pi/2 in three pieces; exact enough for |x| < ~1e5, which covers
-// every argument of the path (hue angles in [0, 4*pi], theta in [0, pi/3]).
+// Reduction by pi/2 in two fused steps (pi/2 to ~107 bits); exact enough for |x| < ~1e5, which covers every argument
+// of the path (hue angles in [0, 4*pi], theta in [0, pi/3]).  |x| >= 2^30 is outside the supported range (NaN).
 F3DS_HD double m_sin_kernel(double r) {
     const double z = r * r;
     const double p = m_estrin8(-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0, 1.0 / 6227020800.0,
                                -1.0 / 1307674368000.0, 1.0 / 355687428096000.0, z);
-    return r + r * (z * p);
+    return m_fma(r, z * p, r);
 }
 F3DS_HD double m_cos_kernel(double r) {
     const double z = r * r;
-    const double p = m_estrin16(-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0, -1.0 / 87178291200.0,
-                                1.0 / 20922789888000.0, -1.0 / 6402373705728000.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, z);
-    return 1.0 + z * p;
+    const double p = m_estrin8(1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0, -1.0 / 3628800.0, 1.0 / 479001600.0, -1.0 / 87178291200.0,
+                               1.0 / 20922789888000.0, -1.0 / 6402373705728000.0, z);
+    // 1 - z/2 + z^2 p: the large terms first, exactly like the classic kernel (1 - z/2 is exact to one rounding)
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + z * (z * p));
 }
 F3DS_HD int m_rem_pio2(double x, double* r) {
     const double TWO_OVER_PI = 0.6366197723675814;
-    const double PIO2_1 = 0x1.921fb54400000p+0;      // 33 bits
-    const double PIO2_2 = 0x1.0b4611a600000p-34;     // next 33 bits
-    const double PIO2_3 = 0x1.3198a2e037073p-69;
-    double t = x * TWO_OVER_PI;
-    double nd = (double)(long long)(t + (t < 0.0 ? -0.5 : 0.5));
-    *r = ((x - nd * PIO2_1) - nd * PIO2_2) - nd * PIO2_3;
-    return (int)((long long)nd & 3);
+    const double PIO2_HI = 0x1.921fb54442d18p+0;
+    const double PIO2_LO = 0x1.1a62633145c07p-54;
+    int q;
+    const double nd = m_rint_small(x * TWO_OVER_PI, &q);
+    *r = m_fma(-nd, PIO2_LO, m_fma(-nd, PIO2_HI, x));
+    return q & 3;
 }
 F3DS_HD double m_sin(double x) {
-    if (m_isnan(x) || m_isinf(x)) return m_nan();
-    if (m_abs(x) <= 0.7853981633974483) return m_sin_kernel(x);
-    if (m_abs(x) > 1.0e15) return m_nan();          // outside the supported range (documented)
-    double r; int q = m_rem_pio2(x, &r);
-    switch (q) {
-        case 0: return m_sin_kernel(r);
-        case 1: return m_cos_kernel(r);
-        case 2: return -m_sin_kernel(r);
-        default: return -m_cos_kernel(r);
-    }
+    if (!(m_abs(x) < 0x1p30)) return m_nan();          // NaN, infinity, outside the supported range (documented)
+    double r; const int q = m_rem_pio2(x, &r);
+    const double v = (q & 1) ? m_cos_kernel(r) : m_sin_kernel(r);
+    return (q & 2) ? -v : v;
 }
 F3DS_HD double m_cos(double x) {
-    if (m_isnan(x) || m_isinf(x)) return m_nan();
-    if (m_abs(x) <= 0.7853981633974483) return m_cos_kernel(x);
-    if (m_abs(x) > 1.0e15) return m_nan();
-    double r; int q = m_rem_pio2(x, &r);
-    switch (q) {
-        case 0: return m_cos_kernel(r);
-        case 1: return -m_sin_kernel(r);
-        case 2: return -m_cos_kernel(r);
-        default: return m_sin_kernel(r);
-    }
+    if (!(m_abs(x) < 0x1p30)) return m_nan();
+    double r; const int q = m_rem_pio2(x, &r);
+    const double v = (q & 1) ? m_sin_kernel(r) : m_cos_kernel(r);
+    return ((q + 1) & 2) ? -v : v;
 }
 
 // ---- atan2 -----------------------------------------------------------------------------
 // atan(t) for t in [0,1]: atan(t) = atan(c) + atan((t-c)/(1+t*c)), c in {0, 1/2, 1}
 F3DS_HD double m_atan01(double t) {
-    double hi, lo, u;
-    if (t < 0.25) { hi = 0.0; lo = 0.0; u = t; }
-    else if (t < 0.75) { hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56; u = (t - 0.5) / (1.0 + 0.5 * t); }
-    else { hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55; u = (t - 1.0) / (1.0 + t); }
+    // branch-free choice of c (a wave evaluates this for many lanes at once: every taken branch would be executed by all)
+    const bool lo_r = t < 0.25, mid_r = t < 0.75;
+    const double c = lo_r ? 0.0 : (mid_r ? 0.5 : 1.0);
+    const double hi = lo_r ? 0.0 : (mid_r ? 0x1.dac670561bb4fp-2 : 0x1.921fb54442d18p-1);
+    const double lo = lo_r ? 0.0 : (mid_r ? 0x1.a2b7f222f65e2p-56 : 0x1.1a62633145c07p-55);
+    const double u = (t - c) / m_fma(c, t, 1.0);     // c = 0: t / 1 = t exactly
     const double z = u * u;                          // <= 0.0625
-    const double p = m_estrin16(-1.0 / 3.0, 1.0 / 5.0, -1.0 / 7.0, 1.0 / 9.0, -1.0 / 11.0, 1.0 / 13.0, -1.0 / 15.0, 1.0 / 17.0, -1.0 / 19.0,
-                                1.0 / 21.0, -1.0 / 23.0, 1.0 / 25.0, -1.0 / 27.0, 1.0 / 29.0, -1.0 / 31.0, 1.0 / 33.0, z);
-    double a = u + u * (z * p);
+    // 14 terms: z^14/29 < 5e-19
+    const double p = m_estrin14(-1.0 / 3.0, 1.0 / 5.0, -1.0 / 7.0, 1.0 / 9.0, -1.0 / 11.0, 1.0 / 13.0, -1.0 / 15.0, 1.0 / 17.0, -1.0 / 19.0,
+                                1.0 / 21.0, -1.0 / 23.0, 1.0 / 25.0, -1.0 / 27.0, 1.0 / 29.0, z);
+    const double a = m_fma(u, z * p, u);
     return hi + (a + lo);
 }
 F3DS_HD double m_atan2(double y, double x) {
-    if (m_isnan(x) || m_isnan(y)) return m_nan();
     const double PI_HI = 0x1.921fb54442d18p+1, PI_LO = 0x1.1a62633145c07p-53;
     const double PIO2_HI = 0x1.921fb54442d18p+0, PIO2_LO = 0x1.1a62633145c07p-54;
-    double ax = m_abs(x), ay = m_abs(y);
+    const double ax = m_abs(x), ay = m_abs(y);
     double a;
-    if (ay == 0.0) {
-        a = m_signbit(x) ? PI_HI : 0.0;
-        return m_copysign(a, y);
+    if (!(ax > 0.0 && ay > 0.0 && ax < m_inf() && ay < m_inf())) {      // zeros, infinities, NaN: the special cases of C99 F.9.1.4
+        if (m_isnan(x) || m_isnan(y)) return m_nan();
+        if (ay == 0.0) { a = m_signbit(x) ? PI_HI : 0.0; return m_copysign(a, y); }
+        if (ax == 0.0) return m_copysign(PIO2_HI, y);
+        if (m_isinf(ax) && m_isinf(ay)) {
+            a = 0x1.921fb54442d18p-1;
+            if (m_signbit(x)) a = (PI_HI - a) + PI_LO;
+            return m_copysign(a, y);
+        }
+        if (m_isinf(ax)) { a = m_signbit(x) ? PI_HI : 0.0; return m_copysign(a, y); }
+        return m_copysign(PIO2_HI, y);
     }
-    if (ax == 0.0) return m_copysign(PIO2_HI, y);
-    if (m_isinf(ax) && m_isinf(ay)) {
-        a = 0x1.921fb54442d18p-1;
-        if (m_signbit(x)) a = (PI_HI - a) + PI_LO;
-        return m_copysign(a, y);
-    }
-    if (m_isinf(ax)) { a = m_signbit(x) ? PI_HI : 0.0; return m_copysign(a, y); }
-    if (m_isinf(ay)) return m_copysign(PIO2_HI, y);
-    if (ax >= ay) a = m_atan01(ay / ax);
-    else a = (PIO2_HI - m_atan01(ax / ay)) + PIO2_LO;
+    const bool steep = ay > ax;
+    a = m_atan01((steep ? ax : ay) / (steep ? ay : ax));
+    if (steep) a = (PIO2_HI - a) + PIO2_LO;
     if (m_signbit(x)) a = (PI_HI - a) + PI_LO;
     return m_copysign(a, y);
 }
@@ -214,10 +220,10 @@ F3DS_HD double m_pow_pos(double x, double y) {       // x > 0
     return m_exp(y * m_log(x));
 }
 F3DS_HD double m_cbrt_pos(double x) {                // x > 0
-    double y = m_exp(m_log(x) / 3.0);
+    double y = m_exp(m_log(x) * 0x1.5555555555555p-2);
     // one Newton step removes the exp/log rounding: y -= (y^3 - x) / (3 y^2)
-    double y2 = y * y;
-    y = y - (y2 * y - x) / (3.0 * y2);
+    const double y2 = y * y;
+    y = y - m_fma(y2, y, -x) / (3.0 * y2);
     return y;
 }
 

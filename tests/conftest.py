@@ -181,6 +181,22 @@ ALL_DEBUG = ["GRID", "VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_XYZ", "VOXEL_RGB", "VOX
              "VOXEL_REGION", "SV_REGION"]
 
 
+def canon(a):
+    """Bytes of an array with every NaN replaced by the canonical quiet NaN: a NaN's sign / payload depends on the compiler's
+    operand order (x86 propagates the first operand's) and on the platform (0/0 is 0xFFC00000 on the host, 0x7FC00000 on the
+    device) and carries no information.  Integer arrays pass unchanged."""
+    a = np.ascontiguousarray(a)
+    if a.dtype.kind == "f":
+        a = a.copy()
+        a[np.isnan(a)] = np.nan
+    return a
+
+
+def sha_of(a):
+    import hashlib
+    return hashlib.sha256(canon(a).tobytes()).hexdigest()
+
+
 def bits_equal(a, b):
     """Bit-for-bit equality (NaN payloads included)."""
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
@@ -190,6 +206,7 @@ def bits_equal(a, b):
 def first_mismatch(name, a, b):
     if a.shape != b.shape:
         return "%s: shape %s vs %s" % (name, a.shape, b.shape)
+    a, b = canon(a), canon(b)
     d = np.nonzero(a.view(np.uint8).reshape(-1) != b.view(np.uint8).reshape(-1))[0]
     if len(d) == 0:
         return None

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALL_DEBUG, ROOT, first_mismatch
+from conftest import sha_of, ALL_DEBUG, ROOT, first_mismatch
 
 pytestmark = pytest.mark.gpu
 BIG = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))      # tools/make_golden_big.py
@@ -15,7 +15,7 @@ SUMMARY = ("n_points", "n_finite", "n_voxels", "octree_depth", "n_seed_cells", "
 
 
 def _sha(a):
-    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    return sha_of(a)
 
 
 def _invariants(P, pts, labels, res):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALL_DEBUG, ROOT, first_mismatch, same_bits
+from conftest import sha_of, ALL_DEBUG, ROOT, first_mismatch, same_bits
 from golden_cases import GOLDEN_CASES, case_params, case_points
 
 pytestmark = pytest.mark.gpu
@@ -31,10 +31,10 @@ def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name):
         if m:
             problems.append(m)
         if not m:       # equal to the oracle run here: then equal to the committed hash too (a mismatch is reported once, below)
-            assert hashlib.sha256(got.tobytes()).hexdigest() == GOLD[name]["sha256"][what], what
+            assert sha_of(got) == GOLD[name]["sha256"][what], what
     assert not problems, "\n".join(problems)
     assert np.array_equal(olab, glab)
-    assert hashlib.sha256(glab.tobytes()).hexdigest() == GOLD[name]["labels_sha256"]
+    assert sha_of(glab) == GOLD[name]["labels_sha256"]
     assert (np.isnan(ores.lambda_) and np.isnan(gres.lambda_)) or ores.lambda_ == gres.lambda_
     ox, ol, oc = oh.voxel_cloud()
     gx, gl, gc = gpu_ctx.voxel_cloud()
@@ -270,7 +270,7 @@ def test_dirty_tile_sweeps_are_bit_identical_at_any_setting(P, shift):
         "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
         "for n in %r:\n"
         "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
-        "    out[n] = dict(labels=hashlib.sha256(lab.tobytes()).hexdigest(), **{w: hashlib.sha256(ctx.debug(w).tobytes()).hexdigest() for w in ('VOXEL_SVLABEL', 'VOXEL_DIST', 'SV_CENTROID', 'MERGES')})\n"
+        "    out[n] = dict(labels=conftest.sha_of(lab), **{w: conftest.sha_of(ctx.debug(w)) for w in ('VOXEL_SVLABEL', 'VOXEL_DIST', 'SV_CENTROID', 'MERGES')})\n"
         "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
     env = dict(os.environ, F3DS_INC_SHIFT=shift)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
@@ -295,7 +295,7 @@ def test_merge_kernel_with_keys_in_global_memory(P):
         "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
         "for n in %r:\n"
         "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
-        "    out[n] = dict(labels=hashlib.sha256(lab.tobytes()).hexdigest(), MERGES=hashlib.sha256(ctx.debug('MERGES').tobytes()).hexdigest())\n"
+        "    out[n] = dict(labels=conftest.sha_of(lab), MERGES=conftest.sha_of(ctx.debug('MERGES')))\n"
         "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F3DS_FORCE_BIG_MERGE="1"))
     assert r.returncode == 0, r.stderr[-2000:]
@@ -306,6 +306,7 @@ def test_merge_kernel_with_keys_in_global_memory(P):
 
 
 MERGE_VARIANTS = [dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="global"),
+                  dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="global"),
                   dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="global"),
                   dict(F3DS_MERGE_KERNEL="old"), dict(F3DS_MERGE_KERNEL="old", F3DS_FORCE_BIG_MERGE="1")]
 
@@ -324,8 +325,8 @@ def test_every_merge_kernel_layout_gives_the_oracle_merges(P, oracle, monkeypatc
     for n in ["rgbd_320x240_ghosts", "rgbd_160x120_equalization", "fixture_launch_flags", "fused_200k_nan_lambda", "rgbd_320x240_large_supervoxels",
               "rgbd_160x120_threshold_1", "rgbd_160x120_rgb_metric"]:
         lab = ctx.segment(case_points(P, n), case_params(P, n))
-        assert hashlib.sha256(lab.tobytes()).hexdigest() == gold[n]["labels_sha256"], n
-        assert hashlib.sha256(ctx.debug("MERGES").tobytes()).hexdigest() == gold[n]["sha256"]["MERGES"], n
+        assert sha_of(lab) == gold[n]["labels_sha256"], n
+        assert sha_of(ctx.debug("MERGES")) == gold[n]["sha256"]["MERGES"], n
     # voxel cloud order (leaf arrays of the merged regions) and region records against the oracle run here
     pts = case_points(P, "rgbd_320x240_ghosts"); prm = case_params(P, "rgbd_320x240_ghosts")
     rc, olab, ores, oh = oracle.segment(pts, prm)
@@ -335,8 +336,8 @@ def test_every_merge_kernel_layout_gives_the_oracle_merges(P, oracle, monkeypatc
     for seed in (1000, 1061):
         e = big["config5_seed%d" % seed]
         lab = ctx.segment(P.synth_frame(*e["synth"]), P.launch_params(**e["params"]))
-        assert hashlib.sha256(lab.tobytes()).hexdigest() == e["labels_sha256"], seed
-        assert hashlib.sha256(ctx.debug("MERGES").tobytes()).hexdigest() == e["sha256"]["MERGES"], seed
+        assert sha_of(lab) == e["labels_sha256"], seed
+        assert sha_of(ctx.debug("MERGES")) == e["sha256"]["MERGES"], seed
     ctx.close()
 
 

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import same_bits, ALL_DEBUG, FIXTURE_PCD, ROOT
+from conftest import sha_of, same_bits, ALL_DEBUG, FIXTURE_PCD, ROOT
 from golden_cases import GOLDEN_CASES, case_params, case_points
 
 KAT = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kat.json")))
@@ -108,8 +108,8 @@ def test_golden(P, oracle, emul, name, which):
         got = getattr(res, k)
         assert (v == "nan" and got != got) or got == v, k
     for w in ALL_DEBUG:
-        assert hashlib.sha256(h.get(w).tobytes()).hexdigest() == g["sha256"][w], w
-    assert hashlib.sha256(labels.tobytes()).hexdigest() == g["labels_sha256"]
+        assert sha_of(h.get(w)) == g["sha256"][w], w
+    assert sha_of(labels) == g["labels_sha256"]
     if "merges" in g:
         assert h.get("MERGES").reshape(-1, 3).tolist() == g["merges"]
 

@@ -10,7 +10,7 @@ import hashlib, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import ALL_DEBUG, CpuChecker, FIXTURE_PCD, pkg
+from conftest import sha_of, ALL_DEBUG, CpuChecker, FIXTURE_PCD, pkg
 from golden_cases import GOLDEN_CASES, case_points, case_params
 
 P = pkg()
@@ -22,8 +22,8 @@ for name in GOLDEN_CASES:
     rc, labels, res, h = ora.segment(pts, prm)
     assert rc == 0, (name, rc)
     entry = {"summary": {k: (v if not isinstance(v, float) or v == v else "nan") for k, v in res.as_dict().items() if k not in ("ms_stage", "ms_total")},
-             "sha256": {w: hashlib.sha256(h.get(w).tobytes()).hexdigest() for w in ALL_DEBUG},
-             "labels_sha256": hashlib.sha256(labels.tobytes()).hexdigest(),
+             "sha256": {w: sha_of(h.get(w)) for w in ALL_DEBUG},
+             "labels_sha256": sha_of(labels),
              "label_histogram": np.bincount(labels[labels != 0xFFFFFFFF]).tolist()[:64],
              "unlabelled_points": int((labels == 0xFFFFFFFF).sum())}
     if res.n_merges <= 400:

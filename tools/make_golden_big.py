@@ -15,7 +15,7 @@ SUMMARY = ("n_points", "n_finite", "n_voxels", "octree_depth", "n_seed_cells", "
 
 
 def run(job):
-    from conftest import CpuChecker, pkg
+    from conftest import sha_of, CpuChecker, pkg
     P = pkg()
     ora = CpuChecker(os.path.join(ROOT, "oracle", "libf3ds_oracle.so"), "f3ds_oracle")
     name, synth, over, arrays = job
@@ -24,8 +24,8 @@ def run(job):
     rc, labels, res, h = ora.segment(pts, prm)
     assert rc == 0, (name, rc)
     e = {"synth": list(synth), "params": over, "summary": {k: getattr(res, k) for k in SUMMARY},
-         "labels_sha256": hashlib.sha256(labels.tobytes()).hexdigest(),
-         "sha256": {w: hashlib.sha256(h.get(w).tobytes()).hexdigest() for w in arrays}}
+         "labels_sha256": sha_of(labels),
+         "sha256": {w: sha_of(h.get(w)) for w in arrays}}
     h.close()
     print(name, e["summary"], flush=True)
     return name, e

@@ -11,6 +11,7 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = [P.synth_frame(0, 1000 + i, 1000, 1000, 30) for i in range(min(nb, 8))]
 ctxs = [P.Context(0) for _ in range(nb)]
 VARIANTS = [dict(F3DS_MERGE_KERNEL="old"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="global"),
+            dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="lds"),
             dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="global")]
 for v in VARIANTS:
     for k in ("F3DS_MERGE_KERNEL", "F3DS_MERGE_NW", "F3DS_MERGE_KEYS"):
