@@ -123,6 +123,15 @@ def load_library(path=None):
     lib.f3ds_get_refined_supervoxels.argtypes = [vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_refined_supervoxels.restype = ctypes.c_int
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
     lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
+    lib.f3ds_get_region_adjacency.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_region_adjacency.restype = ctypes.c_int
+    lib.f3ds_multi_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_multi_create.restype = ctypes.c_int
+    lib.f3ds_multi_destroy.argtypes = [vp]; lib.f3ds_multi_destroy.restype = None
+    lib.f3ds_multi_devices.argtypes = [vp]; lib.f3ds_multi_devices.restype = ctypes.c_int
+    lib.f3ds_multi_device_of_frame.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_device_of_frame.restype = ctypes.c_int
+    lib.f3ds_multi_segment.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.c_int, ctypes.POINTER(Params), ctypes.POINTER(vp), ctypes.POINTER(Result)]
+    lib.f3ds_multi_segment.restype = ctypes.c_int
+    lib.f3ds_multi_gathered_labels.argtypes = [vp]; lib.f3ds_multi_gathered_labels.restype = vp
+    lib.f3ds_multi_last_error.restype = ctypes.c_char_p
     lib.f3ds_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_stream_create.restype = ctypes.c_int
     lib.f3ds_stream_destroy.argtypes = [vp]; lib.f3ds_stream_destroy.restype = None
     lib.f3ds_stream_buffer.argtypes = [vp, sz, ctypes.POINTER(vp)]; lib.f3ds_stream_buffer.restype = ctypes.c_int
@@ -333,6 +342,14 @@ class Context:
         _check(self.lib, self.lib.f3ds_get_supervoxel_adjacency(self.handle, pairs.ctypes.data, n.value, ctypes.byref(n)))
         return pairs
 
+    def region_adjacency(self):
+        """get_currentstate().second after cluster(): (K, 2) array of surviving supervoxel labels a < b, sorted."""
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_region_adjacency(self.handle, None, 0, ctypes.byref(n)))
+        pairs = np.zeros((n.value, 2), np.uint32)
+        _check(self.lib, self.lib.f3ds_get_region_adjacency(self.handle, pairs.ctypes.data, n.value, ctypes.byref(n)))
+        return pairs
+
     def voxel_cloud(self):
         n = ctypes.c_size_t()
         _check(self.lib, self.lib.f3ds_get_voxel_cloud(self.handle, None, None, None, 0, ctypes.byref(n)))
@@ -435,6 +452,55 @@ class FrameStream:
             i += 1
         while self.pending():
             yield self.next()
+
+
+class MultiGpu:
+    """f3ds_multi_*: a batch of independent frames sharded over the GPUs of one node from ONE process (frame i on
+    devices[i mod G], one host thread per GPU inside the library), per-point labels gathered on devices[0] over RCCL and
+    returned as host arrays.  The torch.distributed form of the same partitioning (one process per GPU) is batch.py."""
+
+    def __init__(self, devices=None, n_devices=None, max_frames_per_device=8):
+        self.lib = load_library()
+        if devices is not None:
+            arr = (ctypes.c_int * len(devices))(*devices); n = len(devices)
+        else:
+            arr = None; n = int(n_devices or 1)
+        h = ctypes.c_void_p()
+        rc = self.lib.f3ds_multi_create(arr, n, int(max_frames_per_device), ctypes.byref(h))
+        if rc:
+            raise F3dsError(rc, self.lib.f3ds_strerror(rc).decode() + " " + self.lib.f3ds_multi_last_error().decode())
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.f3ds_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def devices(self):
+        return self.lib.f3ds_multi_devices(self.handle)
+
+    def device_of_frame(self, frame):
+        return self.lib.f3ds_multi_device_of_frame(self.handle, frame)
+
+    def segment(self, frames, params):
+        """frames: list of (N_i, 4) float32 arrays.  Returns (list of label arrays, list of Result)."""
+        k = len(frames)
+        vp = ctypes.c_void_p
+        arrs = [np.ascontiguousarray(f, np.float32).reshape(-1, 4) for f in frames]
+        out = [np.empty(len(a), np.uint32) for a in arrs]
+        pp = (vp * max(k, 1))(*[vp(a.ctypes.data) for a in arrs]); lp = (vp * max(k, 1))(*[vp(o.ctypes.data) for o in out])
+        cnt = (ctypes.c_size_t * max(k, 1))(*[len(a) for a in arrs])
+        results = (Result * max(k, 1))()
+        rc = self.lib.f3ds_multi_segment(self.handle, pp, cnt, k, ctypes.byref(params), lp, results)
+        if rc:
+            raise F3dsError(rc, self.lib.f3ds_strerror(rc).decode() + " " + self.lib.f3ds_multi_last_error().decode() + " " + self.lib.f3ds_last_hip_error().decode())
+        return out, [results[i] for i in range(k)]
 
 
 def segment_batch(ctxs, points, params, labels_out=None, n=None, on_device=False, raw_host=False):

@@ -4,10 +4,12 @@
 //
 // Kept from the reference: -d/-p, -v -s -c -z -n, -t, --RGB --CVX --ML --AL --EQ, -r, -f, --NT, --V.
 // Added (additive): -o <pcd> coloured voxel cloud (Clustering::get_colored_cloud), --labels <file>
-// per-point uint32 region ids, --gpu <id>, --refine <n> (refineSupervoxels, :369-375), --stream <depth> (label files only: the files go through the frame
+// per-point uint32 region ids, --gpu <id>, --gpus <N> (label files only: the files are sharded over N GPUs, file i on GPU i mod N, one host thread per
+// GPU, labels gathered on GPU 0 over RCCL: f3ds_multi_*), --dump <dir> (what visualize() draws, as PCD files), --refine <n> (refineSupervoxels, :369-375), --stream <depth> (label files only: the files go through the frame
 // pipeline f3ds_stream_*, reading ahead of the GPU, no evaluation).  Without -t the threshold is chosen by the ground-truth sweep
 // (all_thresh 0.8..1 step 0.005 + best_thresh, :428-437) and the <-f name>_*.csv score files are written
 // (:471, manageAllPerformances); every file is scored against its `label` field (:462-463).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +39,17 @@ void parse(int argc, char** argv, const char* name, int& v) {
 void parse(int argc, char** argv, const char* name, std::string& v) {
     int i = find_argument(argc, argv, name);
     if (i > 0 && i + 1 < argc) v = argv[i + 1];
+}
+// PCD v0.7 binary file of pcl::PointNormal-like records (x y z normal_x normal_y normal_z): makeSupervoxelNormalCloud's output
+bool write_normal_pcd(const std::string& path, const std::vector<float>& xyz, const std::vector<float>& nrm, size_t n) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z\nSIZE 4 4 4 4 4 4\nTYPE F F F F F F\nCOUNT 1 1 1 1 1 1\n"
+               "WIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary\n", n, n);
+    for (size_t i = 0; i < n; ++i) { fwrite(&xyz[3 * i], 4, 3, f); fwrite(&nrm[3 * i], 4, 3, f); }
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok;
 }
 bool verbose = false;
 #define DEBUG(...) do { if (verbose) fprintf(stderr, __VA_ARGS__); } while (0)
@@ -68,6 +81,8 @@ int main(int argc, char** argv) {
                " -o <out.pcd>                   (writes the coloured voxel cloud) \n\t"
                " --labels <file>                (writes per-point uint32 region ids) \n\t"
                " --gpu <id>                     (HIP device, default 0) \n\t"
+               " --gpus <N>                     (with -t and --labels: files sharded over N GPUs, labels gathered on GPU 0 over RCCL) \n\t"
+               " --dump <dir>                   (voxel centroids, supervoxel normals, adjacency graph, refined cloud as PCD: what the viewer shows) \n\t"
                " --stream <depth>               (with -t and --labels: files through the frame pipeline, <depth> in flight) \n\t"
                " --refine <iterations>          (refineSupervoxels as main() does with 3, :369-375; with -o also <out.pcd>.refined) \n",
                argv[0]);
@@ -127,6 +142,9 @@ int main(int argc, char** argv) {
     prm.lambda = lambda; prm.bins = bin_num; prm.threshold = thresh; prm.fold_negative_z = 1;
     int refine_itr = 0;
     if (find_switch(argc, argv, "--refine")) parse(argc, argv, "--refine", refine_itr);
+    std::string dump_dir;
+    if (find_switch(argc, argv, "--dump")) parse(argc, argv, "--dump", dump_dir);
+    if (!dump_dir.empty() && refine_itr <= 0) refine_itr = 3;      // main() refines with 3 iterations for the normals the viewer shows (:371)
     int stream_depth = 0;
     if (find_switch(argc, argv, "--stream")) parse(argc, argv, "--stream", stream_depth);
     if (stream_depth > 0) {
@@ -165,6 +183,46 @@ int main(int argc, char** argv) {
         }
         while (f3ds_stream_pending(fs) > 0) take(1);
         f3ds_stream_destroy(fs);
+        return failed;
+    }
+    int gpus = 0;
+    if (find_switch(argc, argv, "--gpus")) parse(argc, argv, "--gpus", gpus);
+    if (gpus > 0) {
+        // Multi-GPU batch mode (BASELINE.json config 5): file i -> GPU i mod N, one host thread per GPU, per-point labels
+        // gathered on GPU 0 in one RCCL exchange per chunk, then written.  No ground-truth sweep or scores here.
+        if (!thresh_specified || out_labels.empty() || remove_label) { fprintf(stderr, "--gpus needs -t <threshold> and --labels <file>, and does not take -r\n"); return 1; }
+        const int per_device = 8;                                  // frames per GPU and chunk (config 5: 64 frames on 8 GPUs)
+        f3ds_multi* mg = nullptr;
+        int rc = f3ds_multi_create(nullptr, gpus, per_device, &mg);
+        if (rc) { fprintf(stderr, "f3ds_multi_create(%d GPUs): %s %s %s\n", gpus, f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); return 1; }
+        int failed = 0;
+        const size_t chunk = (size_t)gpus * per_device;
+        for (size_t k0 = 0; k0 < file_list.size() && !failed; k0 += chunk) {
+            const size_t k1 = std::min(file_list.size(), k0 + chunk);
+            std::vector<std::vector<P16>> pts(k1 - k0); std::vector<std::vector<uint32_t>> labels(k1 - k0);
+            std::vector<const void*> pp; std::vector<size_t> cnt; std::vector<uint32_t*> lp; std::vector<f3ds_result> res(k1 - k0);
+            for (size_t k = k0; k < k1; ++k) {
+                size_t n = 0;
+                if (f3ds_pcd_read(file_list[k].c_str(), nullptr, nullptr, 0, &n, nullptr, nullptr) == F3DS_OK) {
+                    pts[k - k0].resize(n);
+                    if (n && f3ds_pcd_read(file_list[k].c_str(), pts[k - k0].data(), nullptr, n, &n, nullptr, nullptr) != F3DS_OK) n = 0;
+                }
+                pts[k - k0].resize(n); labels[k - k0].resize(n);
+                pp.push_back(pts[k - k0].data()); cnt.push_back(n); lp.push_back(labels[k - k0].data());
+            }
+            rc = f3ds_multi_segment(mg, pp.data(), cnt.data(), (int)(k1 - k0), &prm, lp.data(), res.data());
+            if (rc) { fprintf(stderr, "f3ds_multi_segment: %s %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); failed = 1; break; }
+            for (size_t k = k0; k < k1; ++k) {
+                const std::string suffix = file_list.size() > 1 ? "." + std::filesystem::path(file_list[k]).stem().string() : "";
+                FILE* f = fopen((out_labels + suffix).c_str(), "wb");
+                if (!f || fwrite(labels[k - k0].data(), 4, cnt[k - k0], f) != cnt[k - k0]) { fprintf(stderr, "writing %s failed\n", (out_labels + suffix).c_str()); failed = 1; }
+                if (f) fclose(f);
+                const f3ds_result& r = res[k - k0];
+                printf("%s: %llu points, %u voxels, %u supervoxels, %u merges -> %u regions (GPU %d of %d)\n", file_list[k].c_str(), (unsigned long long)r.n_points, r.n_voxels,
+                       r.n_supervoxels, r.n_merges, r.n_regions, f3ds_multi_device_of_frame(mg, (int)(k - k0)), gpus);
+            }
+        }
+        f3ds_multi_destroy(mg);
         return failed;
     }
     f3ds_ctx* ctx = nullptr;
@@ -247,6 +305,50 @@ int main(int argc, char** argv) {
                 if (!f || fwrite(labels.data(), 4, n, f) != n) { fprintf(stderr, "writing %s failed\n", out_labels.c_str()); if (f) fclose(f); f3ds_destroy(ctx); return 1; }
                 fclose(f);
             }
+        }
+        if (!dump_dir.empty()) {
+            // Headless replacement for visualize() (:586-700): the clouds and the graph the viewer would show, as files.
+            //   voxel_centroids.pcd     getVoxelCentroidCloud() (:359)                     "voxel centroids"
+            //   colored_voxels.pcd      Clustering::get_colored_cloud() + region label (:443)  "colored voxels"
+            //   supervoxel_normals.pcd  makeSupervoxelNormalCloud(refined clusters) (:373)  "supervoxel_normals"
+            //   adjacency.csv           get_currentstate().second (:444) with the centroids of supervoxel_clusters.at(label) (:636-672)
+            std::error_code ec;
+            const std::string dir = file_list.size() > 1 ? dump_dir + "/" + std::filesystem::path(file).stem().string() : dump_dir;
+            std::filesystem::create_directories(dir, ec);
+            size_t nv = 0, nc = 0, ns = 0, nr = 0, ne = 0;
+            rc = f3ds_get_voxel_centroid_cloud(ctx, nullptr, nullptr, nullptr, 0, &nv);
+            std::vector<float> vxyz(nv * 3); std::vector<uint32_t> vcol(nv), vsv(nv);
+            if (!rc) rc = f3ds_get_voxel_centroid_cloud(ctx, vxyz.data(), vcol.data(), vsv.data(), nv, &nv);
+            if (!rc) rc = f3ds_pcd_write((dir + "/voxel_centroids.pcd").c_str(), vxyz.data(), vcol.data(), vsv.data(), nv, 1);
+            if (!rc) rc = f3ds_get_voxel_cloud(ctx, nullptr, nullptr, nullptr, 0, &nc);
+            std::vector<float> cxyz(nc * 3); std::vector<uint32_t> clab(nc), ccol(nc);
+            if (!rc) rc = f3ds_get_voxel_cloud(ctx, cxyz.data(), clab.data(), ccol.data(), nc, &nc);
+            if (!rc) rc = f3ds_pcd_write((dir + "/colored_voxels.pcd").c_str(), cxyz.data(), ccol.data(), clab.data(), nc, 1);
+            if (!rc) rc = f3ds_get_refined_supervoxels(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &nr);
+            std::vector<uint32_t> rlab(nr), rcnt(nr); std::vector<float> rxyz(nr * 3), rrgb(nr * 3), rnrm(nr * 3);
+            if (!rc) rc = f3ds_get_refined_supervoxels(ctx, rlab.data(), rxyz.data(), rrgb.data(), rnrm.data(), rcnt.data(), nr, &nr);
+            if (!rc && !write_normal_pcd(dir + "/supervoxel_normals.pcd", rxyz, rnrm, nr)) rc = F3DS_ERR_IO;
+            if (!rc) rc = f3ds_get_supervoxels(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &ns);
+            std::vector<uint32_t> slab(ns), scnt(ns); std::vector<float> sxyz(ns * 3), srgb(ns * 3), snrm(ns * 3);
+            if (!rc) rc = f3ds_get_supervoxels(ctx, slab.data(), sxyz.data(), srgb.data(), snrm.data(), scnt.data(), ns, &ns);
+            if (!rc) rc = f3ds_get_region_adjacency(ctx, nullptr, 0, &ne);
+            std::vector<uint32_t> pairs(ne * 2);
+            if (!rc) rc = f3ds_get_region_adjacency(ctx, pairs.data(), ne, &ne);
+            if (!rc) {
+                FILE* f = fopen((dir + "/adjacency.csv").c_str(), "w");
+                if (!f) rc = F3DS_ERR_IO;
+                else {
+                    fprintf(f, "label_a,label_b,ax,ay,az,bx,by,bz\n");
+                    for (size_t e = 0; e < ne; ++e) {
+                        const size_t ia = std::lower_bound(slab.begin(), slab.end(), pairs[2 * e]) - slab.begin(), ib = std::lower_bound(slab.begin(), slab.end(), pairs[2 * e + 1]) - slab.begin();
+                        if (ia >= ns || ib >= ns) continue;
+                        fprintf(f, "%u,%u,%.9g,%.9g,%.9g,%.9g,%.9g,%.9g\n", pairs[2 * e], pairs[2 * e + 1], sxyz[3 * ia], sxyz[3 * ia + 1], sxyz[3 * ia + 2], sxyz[3 * ib], sxyz[3 * ib + 1], sxyz[3 * ib + 2]);
+                    }
+                    fclose(f);
+                }
+            }
+            if (rc) { fprintf(stderr, "--dump %s: %s %s\n", dir.c_str(), f3ds_strerror(rc), f3ds_last_hip_error()); f3ds_destroy(ctx); return 1; }
+            printf("Dumped %zu voxel centroids, %zu coloured voxels, %zu refined supervoxel normals, %zu region adjacencies to %s\n", nv, nc, nr, ne, dir.c_str());
         }
     }
     f3ds_destroy(ctx);

@@ -20,7 +20,9 @@
 // reference order inside each reduction.  Built with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <map>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -124,6 +126,7 @@ struct f3ds_ctx {
     int merge_kind = 0;                // which merge kernel the last cluster stage ran (MergeKind)
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
+    uint32_t edge_mult = 32;           // adjacency list room per seed (S0 * edge_mult + 1024), grown on demand
     int refined_itr = -1;              // >= 0: the r_* buffers hold the state after that many refinement iterations of this frame
     int idxbits = -1;                  // >= 0: the sorted point keys carry the point index in their low bits
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
@@ -519,7 +522,7 @@ int seg_supervoxels(f3ds_ctx* c) {
     rec<d_sv_fill>(c, S0 ? S0 : 1u, 0u, (const float*)c->vf.p, (const uint32_t*)c->owner0.p, S0, (const uint32_t*)c->hlo.p, (const uint32_t*)c->hhi.p, (const int*)c->ghost_vox.p,
                    (const unsigned char*)c->ghost_active.p, (const uint32_t*)c->hcount.p, (const uint32_t*)loff, (const float*)c->hc.p, rows, row_voxel, racc0, rcnt0, rrec0, ralive0,
                    c->d_dc, (const uint32_t*)c->htiles.p, (const uint32_t*)c->htcnt.p, V);
-    const uint32_t ecap = S0 * 32u + 1024u;
+    const uint32_t ecap = (uint32_t)std::min<uint64_t>((uint64_t)S0 * c->edge_mult + 1024u, 0x7fffffffu);
     const uint32_t ehcap = pow2_ge((size_t)ecap * 2);
     ENSURE(c->ehk, uint64_t, ehcap, ehk);
     ENSURE(c->ekeys0, uint64_t, ecap, ek0); ENSURE(c->ekeys1, uint64_t, ecap, ek1); ENSURE(c->evals0, uint32_t, ecap, ev0); ENSURE(c->evals1, uint32_t, ecap, ev1);
@@ -566,8 +569,8 @@ bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl, bool keys_global = fa
 // second-generation merge kernel d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
 bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, bool keys_lds, uint32_t budget, MergeLds* xl) {
     memset(xl, 0, sizeof *xl);
-    xl->Ecap = (E + 63u) & ~63u; if (!xl->Ecap) xl->Ecap = 64u;
     const uint32_t T = (uint32_t)nw * 64u;
+    xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
     const uint32_t fixed = xl->Ecap * (keys_lds ? 8u : 4u) + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
     xl->stage_off = (fixed + 15u) & ~15u;
     xl->keys_in_lds = keys_lds ? 1 : 0;
@@ -620,7 +623,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     memset(&m, 0, sizeof m);
     m.E = E; m.S0 = S0; m.threshold = prm->threshold; m.dc = c->d_dc;
     { const uint64_t cap = (uint64_t)E * c->ev_mult + 4096u; m.ev_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }      // weight-history events: grown on demand (run_cluster)
-    ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, E, m.ew); ENSURE(c->eku, uint32_t, ((size_t)E + 63) & ~(size_t)63, m.eku);
+    ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, E, m.ew); ENSURE(c->eku, uint32_t, ((size_t)E + 2047) & ~(size_t)2047, m.eku);      // (Ecap of the widest merge kernel)
     ENSURE(c->ehist, int, E, m.ehist); ENSURE(c->ealive, unsigned char, E, m.ealive);
     ENSURE(c->ev_epoch, uint32_t, m.ev_cap, m.ev_epoch); ENSURE(c->ev_key, uint32_t, m.ev_cap, m.ev_key); ENSURE(c->ev_prev, int, m.ev_cap, m.ev_prev);
     ENSURE(c->racc, float, (size_t)(S0 + 1) * 12, m.racc); ENSURE(c->rrec, float, (size_t)(S0 + 1) * 16, m.rrec);
@@ -820,6 +823,7 @@ int f3ds_create(int device, f3ds_ctx** out) {
     HIPCHECK(hipSetDevice(device));
     f3ds_ctx* c = new f3ds_ctx;
     c->device = device;
+    if (const char* e = getenv("F3DS_EDGE_MULT")) { const int v = atoi(e); if (v >= 1 && v <= 32) c->edge_mult = (uint32_t)v; }      // tests: start with a short adjacency list
     const int rc = [c]() -> int {
         HIPCHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
@@ -955,6 +959,19 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     stage_mark(b, 4);
     // ---- stage 4: supervoxels, adjacency
     if ((rc = for_frames(b, seg_supervoxels)) || (rc = flush_sync(b))) return rc;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        // a frame with more adjacencies than its list holds (tiny supervoxels: 26 neighbours each and more) runs the pass again with four times the room
+        bool again = false;
+        for (f3ds_ctx* c : b.fr) if (c->h_dc->ev_overflow == 3 && c->edge_mult < (1u << 14)) { c->edge_mult *= 4u; again = true; }
+        if (!again) break;
+        if (getenv("F3DS_TRACE_ERR")) fprintf(stderr, "f3ds: adjacency pass of %zu frames runs again with more list room\n", b.fr.size());
+        for (f3ds_ctx* c : b.fr) {
+            c->h_dc->error = 0; c->h_dc->ev_overflow = 0;
+            HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->ev_overflow, 0, sizeof(int), b.st));
+            HIPCHECK(hipMemsetAsync(&c->d_dc->n_edges, 0, sizeof(uint32_t), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->n_alive, 0, sizeof(uint32_t), b.st));
+        }
+        if ((rc = for_frames(b, seg_supervoxels)) || (rc = flush_sync(b))) return rc;
+    }
     uint64_t maxkey = 1;
     for (f3ds_ctx* c : b.fr) {
         if (c->h_dc->error) return trace_err(c->h_dc->error, "supervoxels/adjacency", c);
@@ -1180,6 +1197,31 @@ extern "C" int f3ds_get_supervoxel_adjacency(f3ds_ctx* c, uint32_t* pairs, size_
     int rc;
     if ((rc = fetch(c, c->ea0, E, a)) || (rc = fetch(c, c->eb0, E, b))) return rc;
     for (uint32_t e = 0; e < E; ++e) { pairs[2 * e] = a[e]; pairs[2 * e + 1] = b[e]; }
+    return F3DS_OK;
+}
+
+// Clustering::get_currentstate().second after cluster(): the adjacency of the merged regions, as pairs (a < b) of the
+// surviving supervoxel labels, sorted (src/supervoxel_clustering.cpp:444,465: what visualize() draws as the graph).  Every
+// initial adjacency maps to the labels its two supervoxels ended in; merge() keeps one edge per pair (contains(), clustering.cpp:408-436).
+extern "C" int f3ds_get_region_adjacency(f3ds_ctx* c, uint32_t* pairs, size_t cap_pairs, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> a, b, root;
+    int rc;
+    if ((rc = fetch(c, c->ea0, c->E, a)) || (rc = fetch(c, c->eb0, c->E, b)) || (rc = fetch(c, c->root, c->S0 + 1, root))) return rc;
+    std::vector<uint64_t> keys;
+    for (uint32_t e = 0; e < c->E; ++e) {
+        const uint32_t p = root[a[e]], q = root[b[e]];
+        if (p != q) keys.push_back(((uint64_t)(p < q ? p : q) << 32) | (p < q ? q : p));
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    if (n_out) *n_out = keys.size();
+    if (!pairs) return F3DS_OK;
+    if (cap_pairs < keys.size()) return F3DS_ERR_CAPACITY;
+    for (size_t k = 0; k < keys.size(); ++k) { pairs[2 * k] = (uint32_t)(keys[k] >> 32); pairs[2 * k + 1] = (uint32_t)keys[k]; }
     return F3DS_OK;
 }
 

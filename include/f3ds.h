@@ -183,6 +183,10 @@ int f3ds_get_supervoxels(f3ds_ctx* ctx, uint32_t* label, float* xyz, float* rgb,
 /* getSupervoxelAdjacency (:365) after clear_adjacency: pairs (a < b) of adjacent supervoxel labels, sorted. */
 int f3ds_get_supervoxel_adjacency(f3ds_ctx* ctx, uint32_t* pairs, size_t cap_pairs, size_t* n_out);
 
+/* get_currentstate().second after cluster() (:444): adjacency of the merged regions as sorted pairs (a < b) of the surviving
+ * supervoxel labels -- the graph visualize() draws between the centroids of supervoxel_clusters.at(label) (:636-672). */
+int f3ds_get_region_adjacency(f3ds_ctx* ctx, uint32_t* pairs, size_t cap_pairs, size_t* n_out);
+
 /* ---- evaluation against ground truth and automatic threshold (the path run when -t is omitted) ----
  * Mirrors Testing::eval_performance (src/testing.cpp:239-406) and Clustering::all_thresh / best_thresh
  * (src/clustering.cpp:691-774) on the frame of the last f3ds_segment call.  truth_point_labels holds
@@ -244,6 +248,28 @@ int f3ds_stream_next(f3ds_stream* s, uint32_t* point_labels, size_t cap, size_t*
 int f3ds_stream_peek(f3ds_stream* s, const uint32_t** point_labels, size_t* n_out, uint64_t* tag, f3ds_result* result, int wait);
 /* frames submitted and not taken */
 int f3ds_stream_pending(f3ds_stream* s);
+
+/* ---- multi-GPU batch driver, one process (BASELINE.json config 5: a batch of independent frames sharded over the
+ * GPUs of a node, label output gathered on one GPU).  The reference has no counterpart (single-threaded CLI,
+ * CMakeLists.txt:5).  Frame i runs on devices[i mod n_devices], one host thread per GPU; the per-point labels of all
+ * frames then go to devices[0] in ONE grouped RCCL send/recv exchange (the ragged form of ncclGather, each peer over its
+ * own xGMI link) and from there to the caller's host buffers.  librccl is loaded at run time; with one device no RCCL
+ * call is made (unless F3DS_MULTI_FORCE_RCCL is set: development).  Results per frame are those of f3ds_segment. */
+typedef struct f3ds_multi f3ds_multi;
+/* devices == NULL: devices 0..n_devices-1.  max_frames_per_device bounds one f3ds_multi_segment call. */
+int f3ds_multi_create(const int* devices, int n_devices, int max_frames_per_device, f3ds_multi** out);
+void f3ds_multi_destroy(f3ds_multi* m);
+int f3ds_multi_devices(const f3ds_multi* m);
+/* index into `devices` of the GPU frame `frame` of a call runs on */
+int f3ds_multi_device_of_frame(const f3ds_multi* m, int frame);
+/* points[i]: counts[i] records of 16 B in host memory; point_labels[i]: host buffer of counts[i] uint32 (may be NULL);
+ * results may be NULL.  F3DS_ERR_CAPACITY when n_frames > n_devices * max_frames_per_device. */
+int f3ds_multi_segment(f3ds_multi* m, const void* const* points, const size_t* counts, int n_frames, const f3ds_params* params,
+                       uint32_t* const* point_labels, f3ds_result* results);
+/* the gathered label block on devices[0] after f3ds_multi_segment (device pointer): device d's frames, in frame order, start
+ * at the sum of the point counts of the devices before d */
+const uint32_t* f3ds_multi_gathered_labels(const f3ds_multi* m);
+const char* f3ds_multi_last_error(void);
 
 /* ---- host-side helpers either side of the path (no GPU needed) -------------------------- */
 

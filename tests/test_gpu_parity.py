@@ -669,3 +669,101 @@ def test_refine_supervoxels_random_frames(P, oracle, gpu_ctx):
         want = oh.refine(k); got = gpu_ctx.refine_supervoxels(k)
         for key in want:
             assert want[key].shape == got[key].shape and same_bits(want[key], got[key]), (i, k, key)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_multi_gpu_driver_on_one_gpu(P, oracle, monkeypatch, force_rccl):
+    """f3ds_multi_* (the C++ one-process multi-GPU batch driver) with one device: frames of mixed size, an empty one, results
+    of single calls; a second call reuses contexts and blocks.  With F3DS_MULTI_FORCE_RCCL the label block also travels
+    through a grouped ncclSend / ncclRecv pair (librccl loaded at run time), which is all of the exchange one GPU can show."""
+    if force_rccl:
+        monkeypatch.setenv("F3DS_MULTI_FORCE_RCCL", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    names = ["rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags", "rgbd_160x120", "fused_200k_nan_lambda"]
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.1)
+    frames = [case_points(P, n) for n in names] + [np.zeros((0, 4), np.float32)]
+    mg = P.MultiGpu(n_devices=1, max_frames_per_device=8)
+    assert mg.devices() == 1 and mg.device_of_frame(5) == 0
+    for rep in range(2):
+        use = frames if rep == 0 else frames[1:4]
+        labels, results = mg.segment(use, prm)
+        for f, g, r in zip(use, labels, results):
+            rc, olab, ores, _ = oracle.segment(f, prm)
+            assert rc == 0 and np.array_equal(olab, g)
+            assert r.n_regions == ores.n_regions and r.n_merges == ores.n_merges and r.n_points == len(f)
+    with pytest.raises(P.F3dsError) as e:
+        mg.segment(frames * 2, prm)          # 12 frames > 1 device x 8
+    assert e.value.code == P.ERR_CAPACITY
+    mg.close()
+    with pytest.raises(P.F3dsError):
+        P.MultiGpu(n_devices=P.device_count() + 1)
+
+
+@pytest.mark.gpu
+def test_cli_gpus_and_dump(P, oracle, tmp_path):
+    """--gpus 1 (directory of files through f3ds_multi_*) and --dump <dir> (what visualize() draws,
+    /root/reference/src/supervoxel_clustering.cpp:586-700, as files) against the oracle's getters."""
+    import subprocess
+    exe = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd", "supervoxel_clustering")
+    d = tmp_path / "in"; d.mkdir()
+    frames = {"a": P.synth_frame(0, 21, 160, 120, 30), "b": P.synth_frame(0, 22, 200, 150, 10), "c": P.synth_frame(1, 23, 100, 80, 0)}
+    for k, f in frames.items():
+        P.write_pcd(str(d / (k + ".pcd")), f[:, :3], f[:, 3].copy().view(np.uint32))
+    flags = ["-v", "0.02", "-s", "0.2", "--CVX", "--AL", "-t", "0.2"]
+    prm = P.launch_params(voxel_res=0.02, seed_res=0.2)
+    r = subprocess.run([exe, "-d", str(d), "--gpus", "1", "--labels", str(tmp_path / "lab")] + flags, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    for k, f in frames.items():
+        rc, olab, ores, _ = oracle.segment(P.read_pcd(str(d / (k + ".pcd"))), prm)
+        assert np.array_equal(np.fromfile(str(tmp_path / ("lab." + k)), np.uint32), olab), k
+    # --dump on one file
+    dump = tmp_path / "dump"
+    r = subprocess.run([exe, "-p", str(d / "b.pcd"), "--dump", str(dump)] + flags, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr + r.stdout
+    pts = P.read_pcd(str(d / "b.pcd"))
+    rc, olab, ores, oh = oracle.segment(pts, prm)
+    cloud, sv = P.read_pcd(str(dump / "voxel_centroids.pcd"), with_labels=True)
+    assert np.array_equal(cloud[:, :3].view(np.uint32), oh.get("VOXEL_XYZ").reshape(-1, 3).view(np.uint32)) and np.array_equal(sv, oh.get("VOXEL_SVLABEL"))
+    cloud, lab = P.read_pcd(str(dump / "colored_voxels.pcd"), with_labels=True)
+    ox, ol, oc = oh.voxel_cloud()
+    assert np.array_equal(cloud[:, :3].view(np.uint32), ox.view(np.uint32)) and np.array_equal(lab, ol) and np.array_equal(cloud[:, 3].copy().view(np.uint32), oc)
+    want = oh.refine(3)
+    raw = open(str(dump / "supervoxel_normals.pcd"), "rb").read()
+    body = np.frombuffer(raw[raw.index(b"DATA binary\n") + 12:], np.float32).reshape(-1, 6)
+    assert np.array_equal(body[:, :3].view(np.uint32), want["xyz"].view(np.uint32)) and np.array_equal(body[:, 3:].view(np.uint32), want["normal"].view(np.uint32))
+    # region adjacency: every initial adjacency mapped to the labels its supervoxels ended in (merge log replayed here)
+    edges = oh.get("EDGES").reshape(-1, 2); merges = oh.get("MERGES").reshape(-1, 3)
+    parent = {}
+    def root(x):
+        while x in parent:
+            x = parent[x]
+        return x
+    for a, b, _ in merges:
+        parent[int(b)] = int(a)
+    exp = sorted({(min(root(int(a)), root(int(b))), max(root(int(a)), root(int(b)))) for a, b in edges if root(int(a)) != root(int(b))})
+    rows = [l.split(",") for l in open(str(dump / "adjacency.csv")).read().splitlines()[1:]]
+    assert [(int(x[0]), int(x[1])) for x in rows] == exp and len(exp) > 0
+    cen = {int(l): c for l, c in zip(oh.get("SV_LABELS"), oh.get("SV_CENTROID").reshape(-1, 10)[:, :3])}
+    for x in rows[:50]:
+        assert np.allclose([float(v) for v in x[2:5]], cen[int(x[0])], rtol=0, atol=1e-6) and np.allclose([float(v) for v in x[5:8]], cen[int(x[1])], rtol=0, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_adjacency_list_regrows_instead_of_failing(P, monkeypatch):
+    """More adjacencies than the list holds (S0 * 32 + 1024 by default) used to be F3DS_ERR_UNSUPPORTED; now the pass runs again with
+    four times the room.  Forced here by starting with S0 * 1 + 1024 (F3DS_EDGE_MULT, read when a context is created)."""
+    monkeypatch.setenv("F3DS_EDGE_MULT", "1")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
+    ctx = P.Context(0)
+    for n in ["rgbd_320x240_ghosts", "fixture_launch_flags"]:
+        lab = ctx.segment(case_points(P, n), case_params(P, n))
+        assert sha_of(lab) == gold[n]["labels_sha256"] and sha_of(ctx.debug("EDGES")) == gold[n]["sha256"]["EDGES"], n
+    e = big["config5_seed1003"]
+    frames = [P.synth_frame(*e["synth"]), case_points(P, "rgbd_160x120")]
+    ctxs = [P.Context(0), P.Context(0)]
+    labs = P.segment_batch(ctxs, frames, P.launch_params(**e["params"]))       # a batch in which only one frame overflows
+    assert ctxs[0].result.n_edges > ctxs[0].result.n_seeds + 1024 and sha_of(labs[0]) == e["labels_sha256"]
+    for c in ctxs + [ctx]:
+        c.close()
