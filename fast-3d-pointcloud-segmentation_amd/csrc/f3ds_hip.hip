@@ -130,7 +130,7 @@ struct f3ds_ctx {
     int refined_itr = -1;              // >= 0: the r_* buffers hold the state after that many refinement iterations of this frame
     int idxbits = -1;                  // >= 0: the sorted point keys carry the point index in their low bits
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
-    MergeDev mdev; MergeLds mlds; uint32_t merge_dyn = 0; float host_lambda = 0.5f;
+    MergeDev mdev; MergeLds mlds; float host_lambda = 0.5f;
     // device scratch (grow-only)
     Buf pts, spts, keys0, keys1, vals0, vals1, flags, incl, tiles, hist, seg_start, pt_voxel, labels;
     Buf vkey, vcount, vf, nbr, nbrT, hkeys, hvals, boxes, ckey, cell_start, chk, chv, chvals, seed_orig, keep, seed_kept;
@@ -544,75 +544,45 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
     rec<d_edge_init>(c, grid_for(E, 256), 0u, (const uint64_t*)c->eks, E, S0, ea0, eb0);
     return F3DS_OK;
 }
-// fits the LDS-resident merge kernel?
-bool merge_fits_lds(uint32_t E, uint32_t S0, MergeLds* xl, bool keys_global = false) {
+// d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
+bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, bool keys_lds, MergeLds* xl) {
     memset(xl, 0, sizeof *xl);
-    xl->Ecap = (E + 63u) & ~63u; if (!xl->Ecap) xl->Ecap = 64u;
-    xl->G = xl->Ecap / 64u;
-    const uint32_t lds_budget = 160u * 1024u - 8192u;     // static LDS of the kernel (scan scratch, scalars)
-    const uint32_t lds_rest = xl->G * 8u + (2u * ML_THREADS + 1u) * 4u + 4u * ML_TL_CAP * 4u + ((xl->G + 15u) & ~15u);
-    // order keys in LDS (8 bytes per edge) when that leaves room for at least 128 staged rows, else in global memory
-    // (4 bytes per edge: d_merge_lds_big), else the global-memory kernel
-    bool ok = false;
-    for (int keys_in_lds = keys_global ? 0 : 1; keys_in_lds >= 0 && !ok; --keys_in_lds) {
-        const uint32_t lds_fixed = xl->Ecap * (keys_in_lds ? 8u : 4u) + lds_rest;
-        xl->stage_off = (lds_fixed + 15u) & ~15u;
-        xl->keys_in_lds = keys_in_lds;
-        ok = xl->stage_off + 128u * 52u <= lds_budget;
-    }
-    ok = ok && S0 <= 65534u && !getenv("F3DS_FORCE_GLOBAL_MERGE");
-    if (ok && getenv("F3DS_FORCE_BIG_MERGE") && xl->keys_in_lds) { xl->keys_in_lds = 0; xl->stage_off = (xl->Ecap * 4u + lds_rest + 15u) & ~15u; }     // tests
-    xl->caprows = ok ? (lds_budget - xl->stage_off) / 52u : 128u;
-    if (xl->caprows > 2048u) xl->caprows = 2048u;
-    return ok;
-}
-// second-generation merge kernel d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
-bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, bool keys_lds, uint32_t budget, MergeLds* xl) {
-    memset(xl, 0, sizeof *xl);
-    const uint32_t T = (uint32_t)nw * 64u;
+    const uint32_t T = (uint32_t)nw * 64u, CH = T < 256u ? T : 256u;
     xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
-    const uint32_t fixed = xl->Ecap * (keys_lds ? 8u : 4u) + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
-    xl->stage_off = (fixed + 15u) & ~15u;
+    const uint64_t fixed = (uint64_t)xl->Ecap * (keys_lds ? 8u : 4u) + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
+    const uint64_t stage_off = (fixed + 15u) & ~(uint64_t)15u;
+    const uint64_t total = stage_off + 2u * CH * 52u;
+    xl->stage_off = (uint32_t)stage_off; xl->lds_bytes = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
     xl->keys_in_lds = keys_lds ? 1 : 0;
-    xl->caprows = 2u * T;
-    xl->G = xl->Ecap / 64u;
-    return xl->stage_off + 2u * T * 52u <= budget && S0 <= 65534u;
+    return total <= 160u * 1024u - 2048u && S0 <= 65534u;      // (2 KB: the kernel's static LDS)
 }
-inline uint32_t merge_cw_lds_bytes(const MergeLds& xl, int nw) { return xl.stage_off + 2u * (uint32_t)nw * 64u * 52u; }
-enum MergeKind { MK_GLOBAL = 0, MK_LDS = 1, MK_LDS_BIG = 2, MK_CW2_KL = 3, MK_CW2_KG = 4, MK_CW4_KL = 5, MK_CW4_KG = 6, MK_CW8_KL = 7, MK_CW8_KG = 8 };
-inline int mk_waves(int kind) { return kind <= MK_CW2_KG ? 2 : (kind <= MK_CW4_KG ? 4 : 8); }
-inline bool mk_keys_lds(int kind) { return kind == MK_CW2_KL || kind == MK_CW4_KL || kind == MK_CW8_KL; }
-// Which merge kernel a batch runs (one dispatch for all its frames).  Many frames: the compact 2-wave workgroup (the
-// merge loops then leave most of every CU to the other batches' kernels); few frames: the 8-wave one (a lone frame's
-// latency).  Development switches: F3DS_MERGE_KERNEL=old|cw, F3DS_MERGE_NW=2|8, F3DS_MERGE_KEYS=lds|global,
-// F3DS_MERGE_COMPACT_MIN=<frames>, and the round-1 F3DS_FORCE_GLOBAL_MERGE / F3DS_FORCE_BIG_MERGE.
+// merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_CW + ((8 waves ? 2 : 0) | (keys global ? 1 : 0))
+enum MergeKind { MK_GLOBAL = 0, MK_CW = 1 };
+inline int mk_waves(int kind) { return ((kind - MK_CW) & 2) ? 8 : 2; }
+inline bool mk_keys_lds(int kind) { return !((kind - MK_CW) & 1); }
+// Which merge kernel a batch runs (one dispatch for all its frames).  Few frames: 8 waves per frame (a lone frame's
+// latency); many: 2 (the loops are bound by instruction issue, not by lanes: two waves do the same work with a quarter of
+// the wave slots, and with the order keys left in global memory -- scanned from L2 -- in 60 KB of LDS).  With 8 waves the
+// keys are in LDS beside the endpoints when they fit; a frame whose endpoints alone do not fit, or with more than 65534 seeds, takes d_merge.  Development switches:
+// F3DS_MERGE_NW=2|8, F3DS_MERGE_KEYS=lds|global, F3DS_MERGE_COMPACT_MIN=<frames>, F3DS_FORCE_GLOBAL_MERGE.
 int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
     if (force_global || getenv("F3DS_FORCE_GLOBAL_MERGE")) return MK_GLOBAL;
-    const char* kern = getenv("F3DS_MERGE_KERNEL");
-    if ((kern && !strcmp(kern, "old")) || getenv("F3DS_FORCE_BIG_MERGE")) {
-        bool all_lds = true, keys_global = false;
-        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_fits_lds(c->E, c->S0, &t)) all_lds = false; else if (!t.keys_in_lds) keys_global = true; }
-        return !all_lds ? MK_GLOBAL : (keys_global ? MK_LDS_BIG : MK_LDS);
-    }
     const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
     const size_t compact_min = e_min ? (size_t)atol(e_min) : 16u;
-    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : (atoi(e_nw) == 4 ? 4 : 8)) : (fr.size() >= compact_min ? 2 : 8);
-    // compact: keys stay in LDS while the workgroup keeps to ~half of a CU's 160 KB (something else fits beside it)
-    const uint32_t full = 160u * 1024u - 2048u;
-    const uint32_t want = nw == 2 ? 96u * 1024u : full;
-    bool kl = !(e_keys && !strcmp(e_keys, "global")), ok = true;
-    for (int pass = 0; pass < 2; ++pass) {
-        ok = true;
-        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, kl, (kl && !(e_keys && !strcmp(e_keys, "lds"))) ? want : full, &t)) ok = false; }
-        if (ok || !kl) break;
-        kl = false;
+    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : 8) : (fr.size() >= compact_min ? 2 : 8);
+    // two waves (batches): the keys stay in global memory even when they would fit -- 60 KB of LDS per frame instead of 96 lets
+    // two merge workgroups, or one and a d_normals workgroup, share a CU (2 170 vs 2 065 Mpoints/s, same box)
+    const bool keys_pref_lds = e_keys ? !strcmp(e_keys, "lds") : nw == 8;
+    for (int kl = keys_pref_lds ? 1 : 0; kl >= ((e_keys && !strcmp(e_keys, "lds")) ? 1 : 0); --kl) {
+        bool ok = true;
+        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, kl != 0, &t)) { ok = false; break; } }
+        if (ok) return MK_CW + ((nw == 8 ? 2 : 0) | (kl ? 0 : 1));
     }
-    if (!ok) return MK_GLOBAL;
-    return nw == 2 ? (kl ? MK_CW2_KL : MK_CW2_KG) : (nw == 4 ? (kl ? MK_CW4_KL : MK_CW4_KG) : (kl ? MK_CW8_KL : MK_CW8_KG));
+    return MK_GLOBAL;
 }
 // stage 4c: Clustering::cluster(threshold) up to the merge loop: working copies, deltas, lambda / cdf, weights
 int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
-    const bool use_lds = kind != MK_GLOBAL, keys_global = kind == MK_LDS_BIG;
+    const bool use_lds = kind != MK_GLOBAL;
     const uint32_t S0 = c->S0, E = c->E;
     // main(): set_merging / set_lambda / set_bins_num (src/supervoxel_clustering.cpp:415-423)
     float lambda = 0.5f; int bins = 500;
@@ -641,8 +611,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     rec_copy(c, m.ea, c->ea0.p, (size_t)E * 4);
     rec_copy(c, m.eb, c->eb0.p, (size_t)E * 4);
     MergeLds xl;
-    if (kind >= MK_CW2_KL) merge_cw_layout(E, S0, mk_waves(kind), mk_keys_lds(kind), 0xFFFFFFFFu, &xl);
-    else merge_fits_lds(E, S0, &xl, keys_global);
+    merge_cw_layout(E, S0, use_lds ? mk_waves(kind) : 8, use_lds && mk_keys_lds(kind), &xl);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u) * c->pool_mult;
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
@@ -677,14 +646,10 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
     switch (c->merge_kind) {
-        case MK_LDS: rec<d_merge_lds>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds); break;
-        case MK_LDS_BIG: rec<d_merge_lds_big>(c, 1u, c->mlds.stage_off + c->mlds.caprows * 52u, c->mdev, c->mlds); break;
-        case MK_CW2_KL: rec<d_merge_cw_t<2, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 2), c->mdev, c->mlds); break;
-        case MK_CW2_KG: rec<d_merge_cw_t<2, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 2), c->mdev, c->mlds); break;
-        case MK_CW4_KL: rec<d_merge_cw_t<4, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 4), c->mdev, c->mlds); break;
-        case MK_CW4_KG: rec<d_merge_cw_t<4, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 4), c->mdev, c->mlds); break;
-        case MK_CW8_KL: rec<d_merge_cw_t<8, true>>(c, 1u, merge_cw_lds_bytes(c->mlds, 8), c->mdev, c->mlds); break;
-        case MK_CW8_KG: rec<d_merge_cw_t<8, false>>(c, 1u, merge_cw_lds_bytes(c->mlds, 8), c->mdev, c->mlds); break;
+        case MK_CW + 0: rec<d_merge_cw_t<2, true>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 1: rec<d_merge_cw_t<2, false>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 2: rec<d_merge_cw_t<8, true>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 3: rec<d_merge_cw_t<8, false>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         default: rec<d_merge>(c, 1u, 0u, c->mdev);
     }
     return F3DS_OK;

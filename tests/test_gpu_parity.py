@@ -283,39 +283,14 @@ def test_dirty_tile_sweeps_are_bit_identical_at_any_setting(P, shift):
             assert got[n][w] == gold[n]["sha256"][w], (n, w, shift)
 
 
-@pytest.mark.gpu
-def test_merge_kernel_with_keys_in_global_memory(P):
-    """d_merge_lds_big (order keys outside LDS, used when a frame has too many adjacencies for 8 bytes per edge) gives
-    the same merges: forced here on golden cases through F3DS_FORCE_BIG_MERGE (read per call)."""
-    import hashlib, json, subprocess, sys
-    names = ["rgbd_320x240_ghosts", "rgbd_160x120_equalization", "fixture_launch_flags"]
-    code = (
-        "import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import conftest; from golden_cases import case_points, case_params\n"
-        "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
-        "for n in %r:\n"
-        "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
-        "    out[n] = dict(labels=conftest.sha_of(lab), MERGES=conftest.sha_of(ctx.debug('MERGES')))\n"
-        "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F3DS_FORCE_BIG_MERGE="1"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = json.loads(r.stdout.strip().splitlines()[-1])
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
-    for n in names:
-        assert got[n]["labels"] == gold[n]["labels_sha256"] and got[n]["MERGES"] == gold[n]["sha256"]["MERGES"], n
-
-
-MERGE_VARIANTS = [dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="global"),
-                  dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="global"),
-                  dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="global"),
-                  dict(F3DS_MERGE_KERNEL="old"), dict(F3DS_MERGE_KERNEL="old", F3DS_FORCE_BIG_MERGE="1")]
+MERGE_VARIANTS = [dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("2", "8") for k in ("lds", "global")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", MERGE_VARIANTS, ids=lambda v: "-".join("%s" % x for x in v.values()))
 def test_every_merge_kernel_layout_gives_the_oracle_merges(P, oracle, monkeypatch, variant):
-    """The merge loop exists as d_merge_cw_t<2 | 8 waves, keys in LDS | global> (chosen by batch size and adjacency count),
-    the round-1 d_merge_lds / d_merge_lds_big and the all-global d_merge: each forced here (switches are read per call)
+    """The merge loop exists as d_merge_cw_t<2 | 8 waves, order keys in LDS | global> (chosen by batch size and by what fits
+    LDS) and as the all-global d_merge: each forced here (switches are read per call)
     on golden cases and on the 1M-point frame (regions of > 30 000 voxels and hundreds of leaves: multi-chunk staging)."""
     for k, v in variant.items():
         monkeypatch.setenv(k, v)

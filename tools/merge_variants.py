@@ -10,11 +10,9 @@ prm = P.launch_params(voxel_res=0.008, seed_res=0.08)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = [P.synth_frame(0, 1000 + i, 1000, 1000, 30) for i in range(min(nb, 8))]
 ctxs = [P.Context(0) for _ in range(nb)]
-VARIANTS = [dict(F3DS_MERGE_KERNEL="old"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="global"),
-            dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="lds"),
-            dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="lds"), dict(F3DS_MERGE_NW="2", F3DS_MERGE_KEYS="global")]
+VARIANTS = [dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("8", "2") for k in ("lds", "global")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")]
 for v in VARIANTS:
-    for k in ("F3DS_MERGE_KERNEL", "F3DS_MERGE_NW", "F3DS_MERGE_KEYS"):
+    for k in ("F3DS_FORCE_GLOBAL_MERGE", "F3DS_MERGE_NW", "F3DS_MERGE_KEYS"):
         os.environ.pop(k, None)
     os.environ.update(v)
     for rep in range(2):
@@ -22,4 +20,4 @@ for v in VARIANTS:
         P.segment_batch(ctxs, [frames[i % len(frames)] for i in range(nb)], prm)
         dt = (time.perf_counter() - t0) * 1e3
     r = ctxs[0].result
-    print("%-55s frames %3d  merge stage %8.2f ms   whole call %8.2f ms  (merges %d)" % (v, nb, r.ms_stage[5], dt, r.n_merges), flush=True)
+    print("%-60s frames %3d  merge stage %8.2f ms   whole call %8.2f ms  (merges %d)" % (v, nb, r.ms_stage[5], dt, r.n_merges), flush=True)
