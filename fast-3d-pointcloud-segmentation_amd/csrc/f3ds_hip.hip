@@ -545,38 +545,37 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
     return F3DS_OK;
 }
 // d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
-bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, bool keys_lds, MergeLds* xl) {
+bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {      // res: 2 = endpoints + keys in LDS, 1 = endpoints, 0 = neither
     memset(xl, 0, sizeof *xl);
     const uint32_t T = (uint32_t)nw * 64u, CH = T < 256u ? T : 256u;
     xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
-    const uint64_t fixed = (uint64_t)xl->Ecap * (keys_lds ? 8u : 4u) + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
+    const uint64_t fixed = (uint64_t)xl->Ecap * 4u * (uint32_t)res + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
     const uint64_t stage_off = (fixed + 15u) & ~(uint64_t)15u;
     const uint64_t total = stage_off + 2u * CH * 52u;
     xl->stage_off = (uint32_t)stage_off; xl->lds_bytes = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
-    xl->keys_in_lds = keys_lds ? 1 : 0;
+    xl->keys_in_lds = res;
     return total <= 160u * 1024u - 2048u && S0 <= 65534u;      // (2 KB: the kernel's static LDS)
 }
-// merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_CW + ((8 waves ? 2 : 0) | (keys global ? 1 : 0))
+// merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_CW + (8 waves ? 3 : 0) + (2 - res)
 enum MergeKind { MK_GLOBAL = 0, MK_CW = 1 };
-inline int mk_waves(int kind) { return ((kind - MK_CW) & 2) ? 8 : 2; }
-inline bool mk_keys_lds(int kind) { return !((kind - MK_CW) & 1); }
-// Which merge kernel a batch runs (one dispatch for all its frames).  Few frames: 8 waves per frame (a lone frame's
-// latency); many: 2 (the loops are bound by instruction issue, not by lanes: two waves do the same work with a quarter of
-// the wave slots, and with the order keys left in global memory -- scanned from L2 -- in 60 KB of LDS).  With 8 waves the
-// keys are in LDS beside the endpoints when they fit; a frame whose endpoints alone do not fit, or with more than 65534 seeds, takes d_merge.  Development switches:
-// F3DS_MERGE_NW=2|8, F3DS_MERGE_KEYS=lds|global, F3DS_MERGE_COMPACT_MIN=<frames>, F3DS_FORCE_GLOBAL_MERGE.
+inline int mk_waves(int kind) { return (kind - MK_CW) >= 3 ? 8 : 2; }
+inline int mk_res(int kind) { return 2 - (kind - MK_CW) % 3; }
+// Which merge kernel a batch runs (one dispatch for all its frames).  Few frames: 8 waves per frame and everything that
+// fits in LDS (a lone frame's latency).  Many: 2 waves (the loops are bound by instruction issue, not by lanes: two waves do
+// the same work with a quarter of the wave slots) and a small LDS footprint, so that several merge workgroups or other
+// kernels' workgroups share a CU: F3DS_MERGE_KEYS=lds|global|none (order keys and endpoints in LDS | endpoints only | neither).
+// A frame whose arrays do not fit, or with more than 65534 seeds, takes d_merge.  Other development switches:
+// F3DS_MERGE_NW=2|8, F3DS_MERGE_COMPACT_MIN=<frames>, F3DS_FORCE_GLOBAL_MERGE.
 int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
     if (force_global || getenv("F3DS_FORCE_GLOBAL_MERGE")) return MK_GLOBAL;
     const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
     const size_t compact_min = e_min ? (size_t)atol(e_min) : 16u;
     const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : 8) : (fr.size() >= compact_min ? 2 : 8);
-    // two waves (batches): the keys stay in global memory even when they would fit -- 60 KB of LDS per frame instead of 96 lets
-    // two merge workgroups, or one and a d_normals workgroup, share a CU (2 170 vs 2 065 Mpoints/s, same box)
-    const bool keys_pref_lds = e_keys ? !strcmp(e_keys, "lds") : nw == 8;
-    for (int kl = keys_pref_lds ? 1 : 0; kl >= ((e_keys && !strcmp(e_keys, "lds")) ? 1 : 0); --kl) {
+    const int first = e_keys ? (!strcmp(e_keys, "lds") ? 2 : (!strcmp(e_keys, "global") ? 1 : 0)) : (nw == 8 ? 2 : 1);
+    for (int res = first; res >= (e_keys ? first : 0); --res) {
         bool ok = true;
-        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, kl != 0, &t)) { ok = false; break; } }
-        if (ok) return MK_CW + ((nw == 8 ? 2 : 0) | (kl ? 0 : 1));
+        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, res, &t)) { ok = false; break; } }
+        if (ok) return MK_CW + (nw == 8 ? 3 : 0) + (2 - res);
     }
     return MK_GLOBAL;
 }
@@ -593,7 +592,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     memset(&m, 0, sizeof m);
     m.E = E; m.S0 = S0; m.threshold = prm->threshold; m.dc = c->d_dc;
     { const uint64_t cap = (uint64_t)E * c->ev_mult + 4096u; m.ev_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }      // weight-history events: grown on demand (run_cluster)
-    ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, E, m.ew); ENSURE(c->eku, uint32_t, ((size_t)E + 2047) & ~(size_t)2047, m.eku);      // (Ecap of the widest merge kernel)
+    ENSURE(c->ea, uint32_t, E, m.ea); ENSURE(c->eb, uint32_t, E, m.eb); ENSURE(c->ew, float, ((size_t)E + 2047) & ~(size_t)2047, m.ew); /* d_merge: weights; d_merge_cw_t<., 0>: endpoints */ ENSURE(c->eku, uint32_t, ((size_t)E + 2047) & ~(size_t)2047, m.eku);      // (Ecap of the widest merge kernel)
     ENSURE(c->ehist, int, E, m.ehist); ENSURE(c->ealive, unsigned char, E, m.ealive);
     ENSURE(c->ev_epoch, uint32_t, m.ev_cap, m.ev_epoch); ENSURE(c->ev_key, uint32_t, m.ev_cap, m.ev_key); ENSURE(c->ev_prev, int, m.ev_cap, m.ev_prev);
     ENSURE(c->racc, float, (size_t)(S0 + 1) * 12, m.racc); ENSURE(c->rrec, float, (size_t)(S0 + 1) * 16, m.rrec);
@@ -611,7 +610,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     rec_copy(c, m.ea, c->ea0.p, (size_t)E * 4);
     rec_copy(c, m.eb, c->eb0.p, (size_t)E * 4);
     MergeLds xl;
-    merge_cw_layout(E, S0, use_lds ? mk_waves(kind) : 8, use_lds && mk_keys_lds(kind), &xl);
+    merge_cw_layout(E, S0, use_lds ? mk_waves(kind) : 8, use_lds ? mk_res(kind) : 0, &xl);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u) * c->pool_mult;
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
@@ -646,10 +645,12 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
     switch (c->merge_kind) {
-        case MK_CW + 0: rec<d_merge_cw_t<2, true>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 1: rec<d_merge_cw_t<2, false>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 2: rec<d_merge_cw_t<8, true>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 3: rec<d_merge_cw_t<8, false>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 0: rec<d_merge_cw_t<2, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 1: rec<d_merge_cw_t<2, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 2: rec<d_merge_cw_t<2, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 3: rec<d_merge_cw_t<8, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 4: rec<d_merge_cw_t<8, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 5: rec<d_merge_cw_t<8, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         default: rec<d_merge>(c, 1u, 0u, c->mdev);
     }
     return F3DS_OK;

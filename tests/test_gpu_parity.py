@@ -283,7 +283,7 @@ def test_dirty_tile_sweeps_are_bit_identical_at_any_setting(P, shift):
             assert got[n][w] == gold[n]["sha256"][w], (n, w, shift)
 
 
-MERGE_VARIANTS = [dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("2", "8") for k in ("lds", "global")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")]
+MERGE_VARIANTS = [dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("2", "8") for k in ("lds", "global", "none")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")]
 
 
 @pytest.mark.gpu
