@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=48, help="timed steps; a step = 64 distinct 1M-point frames per GPU")
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--batch", type=int, default=192, help="most frames per f3ds_segment_batch call")
-    ap.add_argument("--groups", type=int, default=4, help="batch calls in flight per GPU (libf3ds runs up to four on distinct hardware queues)")
+    ap.add_argument("--groups", type=int, default=6, help="batch calls in flight per GPU (libf3ds lends each a stream of its own; measured 4: 2 080, 6: 2 200, 7: 1 990, 8: 1 820 Mpoints/s at --steps 20)")
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--height", type=int, default=1000)
     ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the pinned-host-in / host-out pass (default min(steps, 12); 0 = skip)")
@@ -235,17 +235,19 @@ def main():
         dom = STAGES.index("merge")
         dom_ms = mean_stage[dom]
         achieved = ALG_BYTES_PER_POINT * npts * frames_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = path_traffic = None
+        traffic = path_traffic = path_traffic_min = None
         try:        # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
             pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")))
-            traffic = int(pm["kernels"]["d_merge_lds_t"]["hbm_bytes_per_frame"] * frames_per_launch)
-            path_traffic = int(pm["whole_path_hbm_bytes_per_frame"])
+            traffic = int(pm["kernels"]["d_merge_cw_t"]["hbm_bytes_per_frame"] * frames_per_launch)
+            path_traffic = int(pm["whole_path_hbm_bytes_per_frame"])          # upper bound (every read request taken as 128 bytes)
+            path_traffic_min = int(pm["whole_path_hbm_bytes_per_frame_min"])  # lower bound (64-byte requests in the kernels that gather)
         except Exception:
             pass
         whole = {"achieved": round(ALG_BYTES_PER_POINT * value * 1e6 / world / 1e9, 3), "unit": "GB/s", "frac": round(ALG_BYTES_PER_POINT * value * 1e6 / world / 1e9 / HBM_PEAK_GBS, 6),
-                 "algorithmic_bytes_per_frame": ALG_BYTES_PER_POINT * npts, "traffic_per_frame": path_traffic,
-                 "wasted_ratio": round(path_traffic / (ALG_BYTES_PER_POINT * npts), 2) if path_traffic else None}
-        roofline = {"bound": "hbm", "kernel": "k_batched<d_merge_lds_t<true>>", "stage": "merge", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                 "algorithmic_bytes_per_frame": ALG_BYTES_PER_POINT * npts, "traffic_per_frame": path_traffic, "traffic_per_frame_min": path_traffic_min,
+                 "wasted_ratio": round(path_traffic / (ALG_BYTES_PER_POINT * npts), 2) if path_traffic else None,
+                 "traffic_source": "profiles/r2_pmc_hbm_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every launch of the path, units calibrated in profiles/r2_pmc_calibration.json"}
+        roofline = {"bound": "hbm", "kernel": "k_batched<d_merge_cw_t<2,1>>", "stage": "merge", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                     "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_POINT * npts * frames_per_launch),
@@ -286,12 +288,19 @@ def main():
                            "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
                 "value_host_io": host_io, "single_frame_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(line), flush=True)
     for grp in ctxs:
         for c in grp:
             c.close()
     if dist_on:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line, last on stdout: whatever C libraries have buffered on stdout (RCCL prints a version banner there) goes out first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

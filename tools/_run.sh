@@ -1,3 +1,2 @@
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "merge_kernel_layout" > gpurun_out/r2r_gputest.log 2>&1; grep -E "passed|failed|Error|error" gpurun_out/r2r_gputest.log | tail -5
-timeout 100 python tools/merge_variants.py 1 2>&1 | tee gpurun_out/r2r_variants1.log
-for rep in 1 2; do for v in "F3DS_MERGE_KEYS=global" "F3DS_MERGE_KEYS=none"; do echo -n "$v: "; timeout 120 env $v python bench.py --steps 32 --warmup 8 --host-io-steps 0 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['single_frame_latency_ms'])"; done; done | tee gpurun_out/r2r_ab.log
+F3DS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 20 --warmup 5 --host-io-steps 0 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
+timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --host-io-steps 0 2>/dev/null | tail -1 | cut -c1-200

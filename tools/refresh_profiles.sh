@@ -1,18 +1,27 @@
 #!/bin/bash
-# On the GPU box (through gpurun): everything profiles/ is built from, into gpurun_out/<tag>_*.
+# On the GPU box (through gpurun): everything profiles/r2_* is built from, into gpurun_out/<tag>_*.
 #   tools/refresh_profiles.sh <tag>
-# Then here: cp gpurun_out/<tag>_bench.json profiles/r1_bench.json, the *_kernel_stats.csv of <tag>_stats and
-# <tag>_stats_b32, and tools/pmc_summary.py gpurun_out/<tag>_pmc_fetch gpurun_out/<tag>_pmc_write 96 profiles/r1_pmc_hbm_traffic.json
-tag=${1:-r1}
-cd "$GRAFT_REPO_ROOT" || exit 1
+# Then here: cp the summaries named at the end of this script into profiles/.
+tag=${1:-r2}
+R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 300 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 1536 --warmup 768 --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_b32 -- python3 bench.py --batch 32 --groups 1 --steps 128 --warmup 32 --no-cpu-baseline > gpurun_out/${tag}_stats_b32.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_fetch -- python3 bench.py --batch 96 --groups 1 --steps 96 --warmup 96 --no-cpu-baseline > gpurun_out/${tag}_pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${tag}_pmc_write -- python3 bench.py --batch 96 --groups 1 --steps 96 --warmup 96 --no-cpu-baseline > gpurun_out/${tag}_pmc_write.log 2>&1
-# the raw traces are large: keep the summaries and the counter tables only
-find gpurun_out/${tag}_stats gpurun_out/${tag}_stats_b32 -name "*kernel_trace.csv" -delete
-find gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write -name "*kernel_trace.csv" -delete
-echo done
+# 1. the bench line as the driver runs it, and with the default flags
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_flags.json 2> gpurun_out/${tag}_bench.err
+timeout 600 python3 bench.py > gpurun_out/${tag}_bench.json 2>> gpurun_out/${tag}_bench.err
+# 2. per-kernel times of the same command (four calls in flight: durations include sharing the chip) + what the GPU does over time
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_stats -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --host-io-steps 0 --no-cpu-baseline > $R/gpurun_out/${tag}_stats.log 2>&1
+cd $R; cp $(find /tmp/${tag}_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
+python3 tools/timeline.py /tmp/${tag}_stats 0.45 > gpurun_out/${tag}_timeline.txt 2>&1
+# 3. one call of 192 frames at a time: per-kernel cost without contention
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_iso -- python3 $R/bench.py --groups 1 --batch 192 --steps 9 --warmup 3 --host-io-steps 0 --no-cpu-baseline > $R/gpurun_out/${tag}_iso.log 2>&1
+cd $R; cp $(find /tmp/${tag}_iso -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats_isolated.csv
+# 4. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (one call of 96 frames at a time, equal calls)
+for c in FETCH_SIZE WRITE_SIZE; do
+  cd /tmp && F3DS_BENCH_RAMP=0 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${tag}_pmc_$c -- python3 $R/bench.py --groups 1 --batch 96 --steps 3 --warmup 0 --host-io-steps 0 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
+done
+cd $R
+# the profiled run processes: 2 set-up passes of 96 + 3 steps of 64 + 3 latency frames
+python3 tools/pmc_summary.py /tmp/${tag}_pmc_FETCH_SIZE /tmp/${tag}_pmc_WRITE_SIZE 96 gpurun_out/${tag}_pmc_hbm_traffic.json 387 > gpurun_out/${tag}_pmc_summary.txt 2>&1
+tail -20 gpurun_out/${tag}_pmc_summary.txt
+echo "copy to profiles/: ${tag}_bench.json ${tag}_bench_driver_flags.json ${tag}_kernel_stats.csv ${tag}_kernel_stats_isolated.csv ${tag}_timeline.txt ${tag}_pmc_hbm_traffic.json"
