@@ -1,2 +1,3 @@
-F3DS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 20 --warmup 5 --host-io-steps 0 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 20 --warmup 5 --host-io-steps 0 2>/dev/null | tail -1 | cut -c1-200
+timeout 200 python tools/time_configs.py 2>&1 | tee gpurun_out/r2v_time_configs.log
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/r2v_gputest.log 2>&1; grep -E "passed|failed|Error|error" gpurun_out/r2v_gputest.log | tail -5
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
