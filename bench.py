@@ -247,7 +247,7 @@ def main():
                  "algorithmic_bytes_per_frame": ALG_BYTES_PER_POINT * npts, "traffic_per_frame": path_traffic, "traffic_per_frame_min": path_traffic_min,
                  "wasted_ratio": round(path_traffic / (ALG_BYTES_PER_POINT * npts), 2) if path_traffic else None,
                  "traffic_source": "profiles/r2_pmc_hbm_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every launch of the path, units calibrated in profiles/r2_pmc_calibration.json"}
-        roofline = {"bound": "hbm", "kernel": "k_batched<d_merge_cw_t<2,1>>", "stage": "merge", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "k_batched<d_merge_cw_t<8,2>>", "stage": "merge", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                     "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_POINT * npts * frames_per_launch),

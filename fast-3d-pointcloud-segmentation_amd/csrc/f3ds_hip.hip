@@ -560,16 +560,18 @@ bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {  
 enum MergeKind { MK_GLOBAL = 0, MK_CW = 1 };
 inline int mk_waves(int kind) { return (kind - MK_CW) >= 3 ? 8 : 2; }
 inline int mk_res(int kind) { return 2 - (kind - MK_CW) % 3; }
-// Which merge kernel a batch runs (one dispatch for all its frames).  Few frames: 8 waves per frame and everything that
-// fits in LDS (a lone frame's latency).  Many: 2 waves (the loops are bound by instruction issue, not by lanes: two waves do
-// the same work with a quarter of the wave slots) and a small LDS footprint, so that several merge workgroups or other
-// kernels' workgroups share a CU: F3DS_MERGE_KEYS=lds|global|none (order keys and endpoints in LDS | endpoints only | neither).
+// Which merge kernel a batch runs (one dispatch for all its frames): 8 waves per frame and everything that fits in LDS.  The
+// 2-wave layout (the loops are bound by instruction issue, not by lanes: two waves do the same work with a quarter of the wave
+// slots, and with a small LDS footprint several merge workgroups or other kernels' workgroups share a CU) is kept selectable:
+// F3DS_MERGE_NW=2 or F3DS_MERGE_COMPACT_MIN=<frames per call>; F3DS_MERGE_KEYS=lds|global|none (order keys and endpoints in LDS | endpoints only | neither).
 // A frame whose arrays do not fit, or with more than 65534 seeds, takes d_merge.  Other development switches:
 // F3DS_MERGE_NW=2|8, F3DS_MERGE_COMPACT_MIN=<frames>, F3DS_FORCE_GLOBAL_MERGE.
 int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
     if (force_global || getenv("F3DS_FORCE_GLOBAL_MERGE")) return MK_GLOBAL;
     const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
-    const size_t compact_min = e_min ? (size_t)atol(e_min) : 16u;
+    // default: never -- with six calls in flight both widths give the same throughput (2 140-2 280 vs 2 190-2 200 Mpoints/s) and the
+    // 8-wave launch of a call is over in 50 ms instead of 83
+    const size_t compact_min = e_min ? (size_t)atol(e_min) : (size_t)-1;
     const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : 8) : (fr.size() >= compact_min ? 2 : 8);
     const int first = e_keys ? (!strcmp(e_keys, "lds") ? 2 : (!strcmp(e_keys, "global") ? 1 : 0)) : (nw == 8 ? 2 : 1);
     for (int res = first; res >= (e_keys ? first : 0); --res) {
