@@ -338,11 +338,11 @@ int scan_u32(f3ds_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
 int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint32_t n, int total_bits, uint64_t** keys_out, uint32_t** vals_out, int base_shift = 0) {
     *keys_out = k0; if (vals_out) *vals_out = v0;
     if (total_bits <= 0) return F3DS_OK;
-    const int passes = (total_bits + 7) / 8;
+    const int passes = (total_bits + RS_MAXBITS - 1) / RS_MAXBITS;
     const int per = (total_bits + passes - 1) / passes;
     const uint32_t nb = n ? (n + RS_TILE - 1) / RS_TILE : 1u;
     uint32_t* hist;
-    ENSURE(c->hist, uint32_t, (size_t)256 * nb, hist);
+    ENSURE(c->hist, uint32_t, (size_t)RS_BINS * nb, hist);
     int shift = 0;
     for (int p = 0; p < passes; ++p) {
         const int bits = (total_bits - shift) < per ? (total_bits - shift) : per;
@@ -537,7 +537,7 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
     const uint32_t E = c->E, S0 = c->S0;
     uint32_t *ea0, *eb0; ENSURE(c->ea0, uint32_t, E, ea0); ENSURE(c->eb0, uint32_t, E, eb0);
     uint32_t* evs;
-    { uint32_t* h; ENSURE(c->hist, uint32_t, (size_t)256 * (((size_t)E * 2 + RS_TILE - 1) / RS_TILE + 1), h); }      // also holds the 2E-delta sort of seg_cluster_front, recorded before this one is flushed
+    { uint32_t* h; ENSURE(c->hist, uint32_t, (size_t)RS_BINS * (((size_t)E * 2 + RS_TILE - 1) / RS_TILE + 1), h); }      // also holds the 2E-delta sort of seg_cluster_front, recorded before this one is flushed
     rec<d_iota>(c, grid_for(E, 256), 0u, (uint32_t*)c->evals0.p, E);
     int rc = radix_sort(c, (uint64_t*)c->ekeys0.p, (uint32_t*)c->evals0.p, (uint64_t*)c->ekeys1.p, (uint32_t*)c->evals1.p, E, sort_bits, &c->eks, &evs);
     if (rc) return rc;

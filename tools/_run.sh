@@ -1,1 +1,2 @@
-for rep in 1 2; do for v in "F3DS_MERGE_NW=2" "F3DS_MERGE_NW=8" "F3DS_MERGE_NW=8 F3DS_MERGE_KEYS=global"; do echo -n "$v: "; env $v python bench.py --steps 20 --warmup 5 --host-io-steps 0 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['launch_ms'], d['roofline']['frac'])"; done; done | tee gpurun_out/r2w_nw.log
+timeout 200 python tools/time_configs.py 2>&1 | grep cfg
+F3DS_LIB=$PWD/fast-3d-pointcloud-segmentation_amd/libf3ds_4b486e7.so timeout 200 python tools/time_configs.py 2>&1 | grep cfg
