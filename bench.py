@@ -216,6 +216,25 @@ def main():
                    "what": "same loop, frames in pinned host memory, labels delivered to pinned host memory (no RCCL gather in this pass)"}
         mode["host"] = False
 
+    # the labels the timed region produced, against the oracle's committed hashes (tests/golden/oracle_golden_big.json, made in the
+    # build container by tools/make_golden_big.py): the last step's block holds the frames of seeds 1000 + 64 rank + i
+    parity = None
+    try:
+        import hashlib
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
+        blk = label_blocks[(args.steps - 1) % n_blocks]
+        checked, bad = 0, []
+        for i in range(0, FPS, 8):
+            key = "config5_seed%d" % seeds[i]
+            if key in gold and npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD"):
+                checked += 1
+                if hashlib.sha256(blk[i].cpu().numpy().tobytes()).hexdigest() != gold[key]["labels_sha256"]:
+                    bad.append(seeds[i])
+        if checked:
+            parity = {"frames_checked": checked, "mismatches": bad, "against": "SHA-256 of the oracle's per-point labels (tests/golden/oracle_golden_big.json)"}
+    except Exception as e:      # noqa
+        parity = {"error": repr(e)}
+
     # single-frame latency (one stream, nothing else in flight) for the record
     barrier()
     tl = time.perf_counter()
@@ -287,7 +306,7 @@ def main():
                            "parallelism": ("%d ranks, one per GPU, every rank its own frames" % world) if world > 1 else "1 GPU",
                            "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
-                "value_host_io": host_io, "single_frame_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
+                "value_host_io": host_io, "labels_checked": parity, "single_frame_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
     for grp in ctxs:
         for c in grp:
             c.close()
