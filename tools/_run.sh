@@ -1,2 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "merge_kernel_layout or every_stage or degenerate or random" 2>&1 | grep -E "passed|failed" | tail -2
-for rep in 1 2; do timeout 100 python tools/merge_variants.py 1 2>&1 | grep "'8'.*lds"; F3DS_LIB=$PWD/fast-3d-pointcloud-segmentation_amd/libf3ds_4b486e7.so timeout 100 python tools/merge_variants.py 1 2>&1 | grep "'8'.*'lds'" | sed 's/^/old: /'; done
+D=$PWD/fast-3d-pointcloud-segmentation_amd
+python tools/ab_merge.py $D/libf3ds.so $D/libf3ds_base.so 4 | tee gpurun_out/r2ad_ab.log
