@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of builds of libf3ds.so on the merge stage of one 1M-point frame: alternating subprocess runs, median and minimum
-of the stage's device time.  usage: tools/ab_merge.py <lib A> <lib B> [rounds]   (clock / DVFS noise on one box is ~ +-1 ms: single runs mislead)"""
+of the stage's device time.  usage: tools/ab_merge.py <lib A> <lib B> ... [rounds]   (clock / DVFS noise on one box is ~ +-1 ms: single runs mislead)"""
 import os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
@@ -15,7 +15,7 @@ for r in range(8):
     c.segment(f, prm); ts.append(c.result.ms_stage[5])
 print(" ".join("%%.3f" %% t for t in ts[2:]))
 ''' % ROOT
-libs = sys.argv[1:3]; rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+libs = [a for a in sys.argv[1:] if not a.isdigit()]; rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 4
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
