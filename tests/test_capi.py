@@ -117,3 +117,23 @@ def test_clustering_mirror_error_behaviour(P):
     c.set_merging(P.EQUALIZATION); assert c.get_lambda() == 0.5 and c.get_bins_num() == 500
     with pytest.raises(ValueError):
         c.set_bins_num(-1)
+
+
+def test_multi_gpu_driver_argument_checks_need_no_gpu(P):
+    """f3ds_multi_*: argument errors and the no-device answer come back as codes, never as a crash, without any GPU work."""
+    lib = P.load_library()
+    h = ctypes.c_void_p()
+    assert lib.f3ds_multi_create(None, 1, 8, None) == P.ERR_ARG
+    rc = lib.f3ds_multi_create(None, 0, 8, ctypes.byref(h))
+    assert rc in (P.ERR_ARG, P.ERR_NO_DEVICE) and not h.value
+    if P.device_count() == 0:
+        assert lib.f3ds_multi_create(None, 1, 8, ctypes.byref(h)) == P.ERR_NO_DEVICE and not h.value
+        with pytest.raises(P.F3dsError) as e:
+            P.MultiGpu(n_devices=1)
+        assert e.value.code == P.ERR_NO_DEVICE
+    assert lib.f3ds_multi_devices(None) == 0 and lib.f3ds_multi_device_of_frame(None, 3) == -1
+    prm = P.default_params()
+    assert lib.f3ds_multi_segment(None, None, None, 0, ctypes.byref(prm), None, None) == P.ERR_ARG
+    assert lib.f3ds_multi_gathered_labels(None) is None
+    lib.f3ds_multi_destroy(None)
+    assert isinstance(lib.f3ds_multi_last_error(), bytes)
