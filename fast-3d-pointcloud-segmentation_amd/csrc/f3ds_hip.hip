@@ -196,13 +196,13 @@ int ensure(f3ds_ctx* c, Buf& b, size_t count, T** out) {
 #define ENSURE(buf, T, count, ptr) do { int rc_ = ensure<T>(c, buf, (size_t)(count), &ptr); if (rc_) return rc_; } while (0)
 
 // Workgroups per frame of a wide kernel.  A launch covers all frames of the batch (grid.y = frame), so a frame gets its
-// share of a launch-wide budget of ~6 k workgroups (24 per CU) and the kernels loop (grid-stride) over the rest: with
+// share of a launch-wide budget of ~3 k workgroups (12 per CU) and the kernels loop (grid-stride) over the rest: with
 // 192 frames per launch the streaming kernels of the sweeps run 1.5-2x faster on 32 fat workgroups per frame than on
 // 300 thin ones (per-workgroup prologue: argument pack, counters, stamps), see DESIGN.md 4b.  The hash-probing /
 // gathering kernels want every wave they can get and keep the old cap (grid_wide).  Set per batch call (one host thread).
 thread_local size_t g_grid_cap = 2048;
 size_t grid_cap_for_batch(int frames) {
-    static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 6144;
+    static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
     if (!target) return 2048;
     size_t cap = target / (size_t)(frames > 0 ? frames : 1);
     return cap < 8 ? 8 : (cap > 2048 ? 2048 : cap);
