@@ -9,7 +9,7 @@
 //                d_centroid, d_centroid_mark  
 //   4 summaries  d_sv_fill (payload rows + ordered leaf sums), d_edges, radix sort, d_edge_init,
 //                d_edge_deltas, d_lambda / d_cdf_*, d_edge_weights
-//   5 merge      d_merge_lds / d_merge_lds_big (one persistent workgroup per frame, LDS resident), d_merge (global memory)
+//   5 merge      d_merge_cw_t<2 or 8 waves, LDS residency> (one persistent workgroup per frame), d_merge (global memory)
 //   6 labels     d_roots (+scan), d_point_labels
 // Every frame RECORDS its kernel calls; flush() zips the records of a batch into one dispatch per kernel (grid.y = frame).
 //
