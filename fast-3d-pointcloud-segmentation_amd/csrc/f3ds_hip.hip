@@ -61,8 +61,12 @@ __device__ __forceinline__ void unpack_call(const ArgPack<>&, Done... d) { K{}(d
 template <class K, class T, class... Ts, class... Done>
 __device__ __forceinline__ void unpack_call(const ArgPack<T, Ts...>& p, Done... d) { unpack_call<K>(p.tail, d..., p.head); }
 
+// A kernel body may ask for a register budget (WAVES_PER_SIMD = w: at most 512 / w VGPRs) so that workgroups of OTHER kernels fit beside its own
+// on a CU: the long-running, latency-bound kernels (the merge loop, the voxel normals) otherwise fence whole CUs off for the wide ones.
+template <class K, class = void> struct waves_per_simd { static constexpr int v = 1; };
+template <class K> struct waves_per_simd<K, std::void_t<decltype(K::WAVES_PER_SIMD)>> { static constexpr int v = K::WAVES_PER_SIMD; };
 template <class K, class Pack>
-__global__ __launch_bounds__(K::BLOCK) void k_batched(const Pack* frames) {
+__global__ __launch_bounds__(K::BLOCK, waves_per_simd<K>::v) void k_batched(const Pack* frames) {
     const Pack p = frames[f3ds_frame()];      // XCD-aware (frame, block) mapping: f3ds_kernels.inc
     unpack_call<K>(p);
 }
@@ -551,7 +555,7 @@ bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {  
     xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
     const uint64_t fixed = (uint64_t)xl->Ecap * 4u * (uint32_t)res + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
     const uint64_t stage_off = (fixed + 15u) & ~(uint64_t)15u;
-    const uint64_t total = stage_off + 2u * CH * 52u;
+    const uint64_t total = stage_off + 2u * CH * 52u + 64u;      // (+ 64: the fold loops read up to 16 rows ahead)
     xl->stage_off = (uint32_t)stage_off; xl->lds_bytes = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
     xl->keys_in_lds = res;
     return total <= 160u * 1024u - 2048u && S0 <= 65534u;      // (2 KB: the kernel's static LDS)
