@@ -10,19 +10,15 @@ using namespace f3ds;
 #define N 64
 __device__ inline unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
 
-template <int K> __device__ inline double quad_bcast(double x) {
-    constexpr int ctrl = K | (K << 2) | (K << 4) | (K << 6);
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), ctrl, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), ctrl, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
-}
+#include "../../fast-3d-pointcloud-segmentation_amd/csrc/f3ds_quad.h"
 
-__global__ void k(double* out, unsigned long long* t, const uint32_t* chase, double seed) {
+__global__ void k(double* out, unsigned long long* t, const uint32_t* chase, double seed, int active_waves) {
     __shared__ uint32_t lds[1024];
     const int lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) lds[i] = (i * 37 + 11) & 1023;
     __syncthreads();
+    // active_waves > 0: only that many waves run the chains, the others of the block wait at a barrier (what most waves of a merge workgroup do most of the time)
+    if (active_waves > 0 && (int)(threadIdx.x >> 6) >= active_waves) { __syncthreads(); return; }
     double x = seed + lane * 1e-3; float xf = (float)x;
     uint32_t p = lane;
     int r = 0;
@@ -53,6 +49,11 @@ __global__ void k(double* out, unsigned long long* t, const uint32_t* chase, dou
         x += l1[0];
     }
     {
+        float l1[3] = {50.0f + (float)x, 2.5f, -10.0f}, l2[3] = {60.0f, -3.0f, 20.0f};
+        RUN("n_ciede00_quad", (l1[1] = 2.0f + n_ciede00_quad(l1, l2, lane & 3) * 0.1f, l2[2] = 20.0f - l1[1]))
+        x += l1[0];
+    }
+    {
         float acc[9] = {1.1f, 0.2f, 0.3f, 2.2f, 0.1f, 3.3f, 0.5f, 0.6f, 0.7f}; float cen[3] = {0.1f, 0.2f, 1.0f}, n4[4];
         RUN("n_plane_normal", (n_plane_normal(acc, 50u, cen, n4), acc[0] = 1.1f + n4[0] * 0.01f, acc[4] = 0.1f + n4[1] * 0.01f))
         x += acc[0];
@@ -72,24 +73,28 @@ __global__ void k(double* out, unsigned long long* t, const uint32_t* chase, dou
     RUN("LDS atomicAdd (one address, 64 lanes)", p = atomicAdd(&lds[0], 1u) & 1023)
     RUN("global dependent load (L2 hit)", p = chase[p])
     RUN("quad_bcast f64 x2", x = quad_bcast<0>(x) + quad_bcast<1>(x))
-    RUN("s_barrier (this block)", __syncthreads())
+    if (active_waves == 0) RUN("s_barrier (this block)", __syncthreads())
+    else if (threadIdx.x < 64) { t[r++] = 0; }
     out[threadIdx.x] = x + xf + p;
     t[63] = r;
+    if (active_waves > 0) __syncthreads();
 }
 
 int main() {
     const char* names[] = {"f64 add", "f64 mul", "f64 mul+add (no fma)", "f64 fma", "f64 div", "f64 sqrt", "f32 add", "f32 div", "f32 sqrt", "m_exp", "m_log", "m_sin", "m_cos", "m_atan2",
-                           "m_pow_pos(x,2.4)", "m_cbrt_pos", "n_ciede00 (one lane)", "n_plane_normal", "n_rgb2lab", "n_normals_diff + is_convex", "LDS dependent read",
+                           "m_pow_pos(x,2.4)", "m_cbrt_pos", "n_ciede00 (one lane)", "n_ciede00_quad", "n_plane_normal", "n_rgb2lab", "n_normals_diff + is_convex", "LDS dependent read",
                            "LDS atomicAdd (distinct addresses)", "LDS atomicAdd (one address, 64 lanes)", "global dependent load (L2 hit)", "quad_bcast f64 x2", "s_barrier"};
     double* out; unsigned long long* t; uint32_t* chase;
     hipMalloc(&out, 8 * 1024); hipMalloc(&t, 8 * 64); hipMalloc(&chase, 4 * 65536);
     uint32_t h[65536]; for (int i = 0; i < 65536; ++i) h[i] = (uint32_t)((i * 40503u + 977u) & 65535u);
     hipMemcpy(chase, h, sizeof h, hipMemcpyHostToDevice);
-    for (int threads : {64, 512}) {
-        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, out, t, chase, 1.37); hipDeviceSynchronize(); }
+    const int cfg[4][2] = {{64, 0}, {512, 0}, {512, 1}, {512, 4}};
+    for (int c = 0; c < 4; ++c) {
+        const int threads = cfg[c][0], active = cfg[c][1];
+        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, out, t, chase, 1.37, active); hipDeviceSynchronize(); }
         unsigned long long ht[64]; hipMemcpy(ht, t, sizeof ht, hipMemcpyDeviceToHost);
-        printf("---- %d threads in the block, shader clocks per dependent step (wave 0) ----\n", threads);
-        for (int i = 0; i < (int)ht[63] && i < 26; ++i) printf("%-48s %8.1f\n", names[i], (double)ht[i] / N);
+        printf("---- %d threads in the block, %s, shader clocks per dependent step (wave 0) ----\n", threads, active == 0 ? "all waves run the chains" : (active == 1 ? "wave 0 runs the chains, the others wait at a barrier" : "waves 0-3 run the chains, the others wait at a barrier"));
+        for (int i = 0; i < (int)ht[63] && i < 27; ++i) printf("%-48s %8.1f\n", names[i], (double)ht[i] / N);
     }
     return 0;
 }
