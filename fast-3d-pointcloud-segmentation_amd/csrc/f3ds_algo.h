@@ -428,9 +428,9 @@ F3DS_HD float a_tg(const MergeParams& p, float dg, int* err) {
     if (bin < 0 || bin >= (short)p.bins) { *err = -9; return 0.0f; }
     return p.cdf_g[bin] / 2;
 }
-F3DS_HD float a_edge_weight(const MergeParams& p, const float* rec_first, const float* rec_second, int* err) {
+template <class K = m_lit> F3DS_HD float a_edge_weight(const MergeParams& p, const float* rec_first, const float* rec_second, int* err, K mc = K()) {
     float dc, dg;
-    n_delta_c_g(rec_first, rec_second, p.color_metric, p.geom_metric, &dc, &dg);
+    n_delta_c_g(rec_first, rec_second, p.color_metric, p.geom_metric, &dc, &dg, mc);
     return a_tc(p, dc, err) + a_tg(p, dg, err);
 }
 

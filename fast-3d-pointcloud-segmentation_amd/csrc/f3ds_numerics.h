@@ -118,7 +118,7 @@ F3DS_HD void n_roots2(float b, float c, float r[3]) {
     r[2] = 0.5f * (b + sd);
     r[1] = 0.5f * (b - sd);
 }
-F3DS_HD void n_roots(float m00, float m01, float m02, float m11, float m12, float m22, float r[3]) {
+template <class K = m_lit> F3DS_HD void n_roots(float m00, float m01, float m02, float m11, float m12, float m22, float r[3], K mc = K()) {
     float c0 = m00 * m11 * m22 + 2.0f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 - m22 * m01 * m01;
     float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
     float c2 = m00 + m11 + m22;
@@ -132,8 +132,8 @@ F3DS_HD void n_roots(float m00, float m01, float m02, float m11, float m12, floa
     float q = half_b * half_b + a_3 * a_3 * a_3;
     if (q > 0.0f) q = 0.0f;
     float rho = n_sqrtf(-a_3);
-    float theta = m_atan2f(n_sqrtf(-q), half_b) * inv3;
-    float ct = m_cosf(theta), st = m_sinf(theta);
+    float theta = m_atan2f(n_sqrtf(-q), half_b, mc) * inv3;
+    float ct = m_cosf(theta, mc), st = m_sinf(theta, mc);
     r[0] = c2_3 + 2.0f * rho * ct;
     r[1] = c2_3 - rho * (ct + sqrt3 * st);
     r[2] = c2_3 - rho * (ct - sqrt3 * st);
@@ -222,8 +222,8 @@ F3DS_HD float n_voxel_distance(const float* c, const float* v, float seed_res, f
 
 // rgb2lab (:151-160): /255 then cv::cvtColor(COLOR_RGB2Lab) on a float pixel; analytic sRGB/D65
 // form (OpenCV is not vendored: unpinned)
-F3DS_HD float n_lab_f(float t) {
-    return t > 0.008856f ? (float)m_cbrt_pos((double)t) : 7.787f * t + 16.0f / 116.0f;
+template <class K = m_lit> F3DS_HD float n_lab_f(float t, K mc = K()) {
+    return t > 0.008856f ? (float)m_cbrt_pos((double)t, mc) : 7.787f * t + 16.0f / 116.0f;
 }
 F3DS_HD void n_rgb2lab(const float rgb[3], float lab[3]) {
     float c[3];
@@ -242,9 +242,9 @@ F3DS_HD void n_rgb2lab(const float rgb[3], float lab[3]) {
 
 // lab_ciede00 (:190-294) with kL = kC = kH = 1: float inputs, double intermediates, float result
 F3DS_HD double n_pow7(double x) { double x2 = x * x; double x4 = x2 * x2; return (x4 * x2) * x; }
-F3DS_HD float n_ciede00(const float lab1[3], const float lab2[3]) {
-    const double PI = 3.14159265358979323846;
-    const double P25_7 = 6103515625.0;
+template <class K = m_lit> F3DS_HD float n_ciede00(const float lab1[3], const float lab2[3], K mc = K()) {
+    const double PI = mc(MC_CIE_PI), TWO_PI = mc(MC_CIE_2PI);          // (2.0 * PI is exact: the same double as the table's)
+    const double P25_7 = mc(MC_CIE_25_7);
     float L1 = lab1[0], a1 = lab1[1], b1 = lab1[2];
     float L2 = lab2[0], a2 = lab2[1], b2 = lab2[2];
     double Cab1 = (double)n_sqrtf(a1 * a1 + b1 * b1);
@@ -259,38 +259,38 @@ F3DS_HD float n_ciede00(const float lab1[3], const float lab2[3]) {
     double Cp_prod = Cp2 * Cp1;
     double hp1 = 0.0;
     if ((m_abs(ap1) + (double)m_absf(b1)) != 0.0) {
-        hp1 = m_atan2((double)b1, ap1);
-        if (hp1 < 0) hp1 += 2.0 * PI;
+        hp1 = m_atan2((double)b1, ap1, mc);
+        if (hp1 < 0) hp1 += TWO_PI;
     }
     double hp2 = 0.0;
     if ((m_abs(ap2) + (double)m_absf(b2)) != 0.0) {
-        hp2 = m_atan2((double)b2, ap2);
-        if (hp2 < 0) hp2 += 2.0 * PI;
+        hp2 = m_atan2((double)b2, ap2, mc);
+        if (hp2 < 0) hp2 += TWO_PI;
     }
     double dL = (double)(L2 - L1);
     double dC = Cp2 - Cp1;
     double dhp = hp2 - hp1;
-    if (dhp > PI) dhp -= 2.0 * PI;
-    else if (dhp < -PI) dhp += 2.0 * PI;
+    if (dhp > PI) dhp -= TWO_PI;
+    else if (dhp < -PI) dhp += TWO_PI;
     if (Cp_prod == 0.0) dhp = 0.0;
-    double dH = 2.0 * n_sqrt(Cp_prod) * m_sin(dhp / 2.0);
+    double dH = 2.0 * n_sqrt(Cp_prod) * m_sin(dhp / 2.0, mc);
     double Lp = (double)(L2 + L1) / 2.0;
     double Cp = (Cp1 + Cp2) / 2.0;
     double hp = (hp1 + hp2) / 2.0;
     if (m_abs(hp1 - hp2) > PI) hp -= PI;
-    if (hp < 0) hp += 2.0 * PI;
+    if (hp < 0) hp += TWO_PI;
     if (Cp_prod == 0.0) hp = hp1 + hp2;
-    double Lpm502 = (Lp - 50.0) * (Lp - 50.0);
-    double T = 1.0 - 0.17 * m_cos(hp - PI / 6.0) + 0.24 * m_cos(2.0 * hp) + 0.32 * m_cos(3.0 * hp + PI / 30.0) -
-               0.20 * m_cos(4.0 * hp - 63.0 * PI / 180.0);
-    double e = (180.0 / PI * hp - 275.0) / 25.0;
-    double dtheta = (30.0 * PI / 180.0) * m_exp(-(e * e));
+    double Lpm502 = (Lp - mc(MC_CIE_50)) * (Lp - mc(MC_CIE_50));
+    double T = 1.0 - mc(MC_CIE_017) * m_cos(hp - mc(MC_CIE_PI_6), mc) + mc(MC_CIE_024) * m_cos(2.0 * hp, mc) + mc(MC_CIE_032) * m_cos(mc(MC_CIE_3) * hp + mc(MC_CIE_PI_30), mc) -
+               mc(MC_CIE_020) * m_cos(4.0 * hp - mc(MC_CIE_63PI_180), mc);
+    double e = (mc(MC_CIE_180_PI) * hp - mc(MC_CIE_275)) / mc(MC_CIE_25);
+    double dtheta = mc(MC_CIE_30PI_180) * m_exp(-(e * e), mc);
     double Cp7 = n_pow7(Cp);
     double Rc = 2.0 * n_sqrt(Cp7 / (Cp7 + P25_7));
-    double kLSL = 1.0 * (1.0 + 0.015 * Lpm502 / n_sqrt(20.0 + Lpm502));
-    double kLSC = 1.0 * (1.0 + 0.045 * Cp);
-    double kHSH = 1.0 * (1.0 + 0.015 * Cp * T);
-    double RT = -m_sin(2.0 * dtheta) * Rc;
+    double kLSL = 1.0 * (1.0 + mc(MC_CIE_0015) * Lpm502 / n_sqrt(mc(MC_CIE_20) + Lpm502));
+    double kLSC = 1.0 * (1.0 + mc(MC_CIE_0045) * Cp);
+    double kHSH = 1.0 * (1.0 + mc(MC_CIE_0015) * Cp * T);
+    double RT = -m_sin(2.0 * dtheta, mc) * Rc;
     double tL = dL / kLSL, tC = dC / kLSC, tH = dH / kHSH;
     return (float)n_sqrt(tL * tL + tC * tC + tH * tH + RT * tC * tH);
 }
@@ -329,9 +329,9 @@ F3DS_HD bool n_is_convex(const float n1[3], const float c1[3], const float n2[3]
 // region record used by the merge stage: 16 floats
 //   [0..2] centroid  [3..5] normal  [6..8] mean rgb  [9..11] Lab of the mean  [12..15] spare
 // delta_c_g (src/clustering.cpp:107-142): first = colour, second = geometry
-F3DS_HD void n_delta_c_g(const float* r1, const float* r2, int color_metric, int geom_metric, float* dc, float* dg) {
+template <class K = m_lit> F3DS_HD void n_delta_c_g(const float* r1, const float* r2, int color_metric, int geom_metric, float* dc, float* dg, K mc = K()) {
     float c;
-    if (color_metric == 0) c = n_ciede00(r1 + 9, r2 + 9) / F3DS_LAB_RANGE;
+    if (color_metric == 0) c = n_ciede00(r1 + 9, r2 + 9, mc) / F3DS_LAB_RANGE;
     else c = n_rgb_eucl(r1 + 6, r2 + 6) / F3DS_RGB_RANGE;
     float g = n_normals_diff(r1 + 3, r1, r2 + 3, r2);
     if (geom_metric == 1 && n_is_convex(r1 + 3, r1, r2 + 3, r2)) g *= 0.5;

@@ -64,6 +64,11 @@ __global__ void k(double* out, unsigned long long* t, const uint32_t* chase, dou
         x += rgb[0];
     }
     {
+        float ch = 120.0f - 30.0f * (lane % 3), lab[3];
+        RUN("rgb -> Lab on three lanes", (lab_three_lanes(ch, lane, lab), ch = 100.0f + lab[1] * 0.1f + (lane % 3)))
+        x += ch;
+    }
+    {
         float r1[16] = {0.1f, 0.2f, 1.0f, 0.0f, 0.6f, 0.8f, 100, 50, 20, 50.0f, 2.5f, -10.0f}, r2[16] = {0.3f, 0.1f, 1.2f, 0.6f, 0.0f, 0.8f, 90, 40, 30, 60.0f, -3.0f, 20.0f};
         RUN("n_normals_diff + is_convex", (r1[0] = 0.1f + n_normals_diff(r1 + 3, r1, r2 + 3, r2) + (n_is_convex(r1 + 3, r1, r2 + 3, r2) ? 0.01f : 0.0f)))
         x += r1[0];
@@ -82,7 +87,7 @@ __global__ void k(double* out, unsigned long long* t, const uint32_t* chase, dou
 
 int main() {
     const char* names[] = {"f64 add", "f64 mul", "f64 mul+add (no fma)", "f64 fma", "f64 div", "f64 sqrt", "f32 add", "f32 div", "f32 sqrt", "m_exp", "m_log", "m_sin", "m_cos", "m_atan2",
-                           "m_pow_pos(x,2.4)", "m_cbrt_pos", "n_ciede00 (one lane)", "n_ciede00_quad", "n_plane_normal", "n_rgb2lab", "n_normals_diff + is_convex", "LDS dependent read",
+                           "m_pow_pos(x,2.4)", "m_cbrt_pos", "n_ciede00 (one lane)", "n_ciede00_quad", "n_plane_normal", "n_rgb2lab", "rgb -> Lab on three lanes", "n_normals_diff + is_convex", "LDS dependent read",
                            "LDS atomicAdd (distinct addresses)", "LDS atomicAdd (one address, 64 lanes)", "global dependent load (L2 hit)", "quad_bcast f64 x2", "s_barrier"};
     double* out; unsigned long long* t; uint32_t* chase;
     hipMalloc(&out, 8 * 1024); hipMalloc(&t, 8 * 64); hipMalloc(&chase, 4 * 65536);
@@ -94,7 +99,7 @@ int main() {
         for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, out, t, chase, 1.37, active); hipDeviceSynchronize(); }
         unsigned long long ht[64]; hipMemcpy(ht, t, sizeof ht, hipMemcpyDeviceToHost);
         printf("---- %d threads in the block, %s, shader clocks per dependent step (wave 0) ----\n", threads, active == 0 ? "all waves run the chains" : (active == 1 ? "wave 0 runs the chains, the others wait at a barrier" : "waves 0-3 run the chains, the others wait at a barrier"));
-        for (int i = 0; i < (int)ht[63] && i < 27; ++i) printf("%-48s %8.1f\n", names[i], (double)ht[i] / N);
+        for (int i = 0; i < (int)ht[63] && i < 28; ++i) printf("%-48s %8.1f\n", names[i], (double)ht[i] / N);
     }
     return 0;
 }
