@@ -397,11 +397,15 @@ int seg_voxels(f3ds_ctx* c) {
     c->hmask = hcap - 1;
     ENSURE(c->vkey, uint32_t, (size_t)V * 3, vkey); ENSURE(c->vcount, uint32_t, V, vcount); ENSURE(c->vf, float, (size_t)V * 12, vf);
     ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hcap, hkeys); ENSURE(c->hvals, uint32_t, hcap, hvals);
-    P16* spts; ENSURE(c->spts, P16, n, spts);
     rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hcap * 8);
-    rec<d_point_gather>(c, grid_wide(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
-    rec<d_voxel_accum>(c, grid_wide(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
-                       (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask);
+    if (getenv("F3DS_SPLIT_VOXEL_ACCUM")) {      // development: round 2's two kernels (a sorted copy of the frame in between)
+        P16* spts; ENSURE(c->spts, P16, n, spts);
+        rec<d_point_gather>(c, grid_wide(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
+        rec<d_voxel_accum>(c, grid_wide(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
+                           (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask);
+    } else
+        rec<d_voxel_gather_accum>(c, grid_wide(V, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, n,
+                                  (const DevCounters*)c->d_dc, c->fa, (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask, (int*)c->pt_voxel.p);
     rec<d_neighbors>(c, grid_wide((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                      c->hmask, nbr, nbrT);
     rec<d_normals>(c, (V + NT_TILE - 1) / NT_TILE, 0u, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
@@ -708,6 +712,31 @@ struct BatchStreamLease {
     ~BatchStreamLease() { if (slot >= 0) { std::lock_guard<std::mutex> lk(g_batch_streams[dev].m); g_batch_streams[dev].busy[slot] = false; } }
 };
 
+// EXPERIMENT (F3DS_MERGE_CUS=<n>): the merge dispatch of a batch goes to a stream whose CU mask holds every (256/n)-th compute unit, so that the merge
+// workgroups of all calls in flight pack onto n CUs (as many per CU as LDS and registers allow) and leave the others to the wide kernels.
+struct MergeStreamPool { std::mutex m; hipStream_t s[8] = {}; bool busy[8] = {}; };
+MergeStreamPool g_merge_streams[16];
+const int g_merge_cus = [] { const char* e = getenv("F3DS_MERGE_CUS"); return e ? atoi(e) : 0; }();
+struct MergeStreamLease {
+    int dev = -1, slot = -1;
+    hipStream_t acquire(int device) {
+        if (g_merge_cus <= 0) return nullptr;
+        MergeStreamPool& p = g_merge_streams[device & 15];
+        std::lock_guard<std::mutex> lk(p.m);
+        if (!p.s[0]) {
+            uint32_t mask[8] = {};
+            const char* e = getenv("F3DS_MERGE_CU_STRIDE"); const int stride = e ? atoi(e) : 256 / g_merge_cus;
+            const char* e0 = getenv("F3DS_MERGE_CU_FIRST"); const int first = e0 ? atoi(e0) : 0;
+            int n = 0;
+            for (int cu = first; cu < 256 && n < g_merge_cus; cu += (stride > 0 ? stride : 1)) { mask[cu >> 5] |= 1u << (cu & 31); n++; }
+            for (int i = 0; i < 8; ++i) if (hipExtStreamCreateWithCUMask(&p.s[i], 8, mask) != hipSuccess) { p.s[i] = nullptr; return nullptr; }
+        }
+        for (int i = 0; i < 8; ++i) if (!p.busy[i] && p.s[i]) { p.busy[i] = true; dev = device & 15; slot = i; return p.s[i]; }
+        return nullptr;
+    }
+    ~MergeStreamLease() { if (slot >= 0) { std::lock_guard<std::mutex> lk(g_merge_streams[dev].m); g_merge_streams[dev].busy[slot] = false; } }
+};
+
 // run `fn` (a per-frame recorder) on every live frame; a failing frame fails the batch
 template <class F>
 int for_frames(Batch& b, F&& fn) {
@@ -723,7 +752,18 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, kind); });
     if (rc || (rc = flush(b))) return rc;
     stage_mark(b, 5);
-    if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
+    {
+        MergeStreamLease ml;
+        hipStream_t ms = all_lds ? ml.acquire(b.fr[0]->device) : nullptr;
+        if (ms) {
+            HIPCHECK(hipStreamSynchronize(b.st));
+            hipStream_t keep = b.st; b.st = ms;
+            rc = for_frames(b, seg_merge); if (!rc) rc = flush(b);
+            if (!rc) HIPCHECK(hipStreamSynchronize(ms));
+            b.st = keep;
+            if (rc) return rc;
+        } else if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
+    }
     stage_mark(b, 6);
     for (size_t i = 0; i < b.fr.size(); ++i) b.fr[i]->user_labels = (labels_on_device && labels_of) ? labels_of[index_of[i]] : nullptr;
     if ((rc = for_frames(b, seg_labels)) || (rc = flush(b))) return rc;
