@@ -384,9 +384,17 @@ int seg_sort(f3ds_ctx* c, int sort_bits, int idxbits) {      // idxbits >= 0: (c
     int rc = radix_sort(c, k0, v0, k1, v1, n, sort_bits, &c->ks, &c->vs, ks);
     if (rc) return rc;
     const uint64_t invalid = 1ull << (3 * c->h_dc->depth);
-    rec<d_heads>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, n, invalid, flags, ks);
-    if ((rc = scan_u32(c, flags, incl, n))) return rc;
-    rec<d_segstart>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, (const uint32_t*)flags, (const uint32_t*)incl, n, invalid, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid, ks);
+    if (getenv("F3DS_SPLIT_VOXEL_ACCUM")) {      // development: round 2's chain (d_point_gather reads the rank array)
+        rec<d_heads>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, n, invalid, flags, ks);
+        if ((rc = scan_u32(c, flags, incl, n))) return rc;
+        rec<d_segstart>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, (const uint32_t*)flags, (const uint32_t*)incl, n, invalid, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid, ks);
+        return F3DS_OK;
+    }
+    const uint32_t nt = n ? (n + SCAN_TILE - 1) / SCAN_TILE : 1u;
+    uint32_t* tiles; ENSURE(c->tiles, uint32_t, nt, tiles);
+    rec<d_seg_count>(c, nt, 0u, (const uint64_t*)c->ks, n, invalid, ks, tiles);
+    rec<d_scan_single>(c, 1u, 0u, tiles, nt);
+    rec<d_seg_write>(c, nt, 0u, (const uint64_t*)c->ks, n, invalid, ks, (const uint32_t*)tiles, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid);
     return F3DS_OK;
 }
 // stage 0c + 1 + 2a: voxel sums, neighbour tables, normals, seed grid growth
