@@ -1119,8 +1119,29 @@ void f3ds_oracle_normal(const float* xyz, size_t n, const float* view_point, flo
     for (size_t i = 0; i < n; ++i) pts[i] = XYZ{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     point_normal(pts.begin(), pts.end(), n, [](const XYZ& p) { return p; }, view_point, normal4, &curv);
 }
-// fn: 0 exp 1 log 2 sin 3 cos 4 atan2 5 cbrt 6 pow(a,b) 7 logf 8 atan2f 9 cosf 10 sinf   (shared-math probes)
+// fn: 0 exp 1 log 2 sin 3 cos 4 atan2 5 cbrt 6 pow(a,b) 7 logf 8 atan2f 9 cosf 10 sinf   (shared-math probes);
+// 100 + fn: the same function with its f64 constants read from a copy of the table (f3ds::m_tab, the provider the merge kernel uses with an LDS copy)
 double f3ds_oracle_math(int fn, double a, double b) {
+    if (fn >= 100) {
+        static double table[f3ds::MC_COUNT];
+        static const bool filled = (f3ds::m_table_fill(table, 0, 1), true);
+        (void)filled;
+        const f3ds::m_tab mc{table};
+        switch (fn - 100) {
+            case 0: return f3ds::m_exp(a, mc);
+            case 1: return f3ds::m_log(a, mc);
+            case 2: return f3ds::m_sin(a, mc);
+            case 3: return f3ds::m_cos(a, mc);
+            case 4: return f3ds::m_atan2(a, b, mc);
+            case 5: return f3ds::m_cbrt_pos(a, mc);
+            case 6: return f3ds::m_pow_pos(a, b, mc);
+            case 7: return (double)f3ds::m_logf((float)a, mc);
+            case 8: return (double)f3ds::m_atan2f((float)a, (float)b, mc);
+            case 9: return (double)f3ds::m_cosf((float)a, mc);
+            case 10: return (double)f3ds::m_sinf((float)a, mc);
+        }
+        return 0;
+    }
     switch (fn) {
         case 0: return f3ds::m_exp(a);
         case 1: return f3ds::m_log(a);

@@ -71,6 +71,21 @@ def test_point_sort_with_key_index_pairs_matches_too(P, oracle, monkeypatch):
     ctx.close()
 
 
+def test_voxel_sums_as_two_kernels_match_too(P, oracle, monkeypatch):
+    """The voxel sums gather their points themselves (d_voxel_gather_accum, segment table from d_seg_count / d_seg_write); the earlier chain
+    (d_heads, scan, d_segstart, d_point_gather, d_voxel_accum) stays behind F3DS_SPLIT_VOXEL_ACCUM (read per call) for A/B runs: same arrays."""
+    monkeypatch.setenv("F3DS_SPLIT_VOXEL_ACCUM", "1")
+    ctx = P.Context(0)
+    for name in ("rgbd_320x240_ghosts", "fixture_launch_flags", "rgbd_160x120_equalization"):
+        pts = case_points(P, name); prm = case_params(P, name)
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        glab = ctx.segment(pts, prm)
+        assert np.array_equal(olab, glab)
+        for what in ("VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_XYZ", "VOXEL_RGB", "POINT_VOXEL"):
+            assert not first_mismatch(what, oh.get(what), ctx.debug(what))
+    ctx.close()
+
+
 def test_recluster_and_clustering_mirror(P, oracle, gpu_ctx):
     """Clustering::cluster(threshold) again on the same supervoxels, with other metrics."""
     pts = case_points(P, "rgbd_160x120")

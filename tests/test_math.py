@@ -32,6 +32,24 @@ def test_double_functions_within_3_ulp(oracle):
     x = np.exp(rng.uniform(-20, 5, n)); assert _ulp_err(_vec(oracle, 5, x), np.cbrt(x)) <= 4
 
 
+def test_constants_from_a_table_give_the_same_bits(oracle):
+    """csrc/f3ds_math.h reads its f64 constants through a provider: literals (m_lit, the default) or a copy of its table (m_tab; the merge
+    kernel keeps one in LDS).  Both must return the same bits, special cases included."""
+    rng = np.random.default_rng(3)
+    n = 100000
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 709.78, 709.79, -745.1, -745.3, 1e-310, 5e-324, 2.2250738585072014e-308,
+                        1.7976931348623157e308, 2.0 ** 30, -2.0 ** 30, 1.4142135623730951, 0.25, 0.75, 1e300, 1e-300])
+    x = np.concatenate([special, rng.uniform(-760, 720, n), np.exp(rng.uniform(-700, 700, n)), rng.uniform(-40, 40, n), rng.standard_normal(n).view(np.float64)])
+    y = np.concatenate([special[::-1], rng.uniform(-100, 100, 3 * n), rng.standard_normal(n).view(np.float64)])
+    bits = rng.integers(0, 2 ** 64, n, dtype=np.uint64).view(np.float64)          # arbitrary bit patterns
+    x = np.concatenate([x, bits]); y = np.concatenate([y, bits[::-1]])
+    for fn in range(11):
+        a = np.abs(x) if fn in (5, 6) else x
+        b = np.full_like(x, 2.4) if fn == 6 else y
+        lit = _vec(oracle, fn, a, b); tab = _vec(oracle, 100 + fn, a, b)
+        assert np.array_equal(lit.view(np.uint64), tab.view(np.uint64)), fn
+
+
 def test_float_wrappers_are_nearly_correctly_rounded(oracle):
     rng = np.random.default_rng(2)
     z = rng.uniform(0.3, 12.0, 200000).astype(np.float32)
