@@ -767,9 +767,10 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
             HIPCHECK(hipStreamSynchronize(b.st));
             hipStream_t keep = b.st; b.st = ms;
             rc = for_frames(b, seg_merge); if (!rc) rc = flush(b);
-            if (!rc) HIPCHECK(hipStreamSynchronize(ms));
-            b.st = keep;
+            const hipError_t se = rc ? hipSuccess : hipStreamSynchronize(ms);
+            b.st = keep;      // (restored on every path)
             if (rc) return rc;
+            HIPCHECK(se);
         } else if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
     }
     stage_mark(b, 6);
