@@ -23,12 +23,18 @@ The JSON line also carries
   value_host_io -- the same loop with the frames in pinned host memory and the labels delivered to
                   pinned host memory (PCIe both ways inside the timed region: what SURVEY.md 8d
                   defines); `value` itself is the HBM-resident rate;
-  roofline     -- dominant kernel by device time (HIP events recorded on the batch's stream inside
-                  libf3ds around each stage): achieved = 20 B/point x points per launch / mean launch
-                  duration, against the 8 TB/s HBM3E peak; `whole_path` = the same for the timed
-                  region as a whole, with the PMC-measured HBM traffic of all kernels of the path;
-  cpu_baseline -- the CPU oracle (single thread, kind "port": the reference needs PCL/OpenCV and
-                  cannot be built here) on one frame of the same workload, rank 0 at N=1 only.
+  roofline     -- dominant kernel by MEASURED device time: two kernels of the path are one launch per
+                  call and bracketed by HIP events on the call's stream inside libf3ds (the merge loop,
+                  the voxel normals); the one with the larger total is named.  achieved = 20 B/point x
+                  points per launch / mean launch duration, against the 8 TB/s HBM3E peak; `stages` =
+                  the same figure for every stage of a call (sequences of many launches); `whole_path`
+                  = the timed region as a whole, with the PMC-measured HBM traffic of all kernels;
+  cpu_baseline -- the CPU oracle (kind "port": the reference needs PCL/OpenCV and cannot be built
+                  here) on the same workload, rank 0 at N=1 only: one frame on one core (the reference
+                  is single-threaded), and `frames_parallel`: the 64-frame batch, one frame per core,
+                  over the host's cores (count stated).
+A label hash that differs from the oracle's committed hashes voids the run: `value` is null and the
+exit code 1.
 """
 import argparse
 import json
@@ -130,7 +136,7 @@ def main():
     gather_stream = torch.cuda.Stream(device=dev) if dist_on else None
     torch.cuda.synchronize()
 
-    stage_ms = [0.0] * 7
+    stage_ms = [0.0] * 8
     calls_done, frames_done = [0], [0]
     stat_lock = threading.Lock()
     mode = {"record": False, "host": False}
@@ -149,7 +155,7 @@ def main():
             P.segment_batch(ctxs[g][:k], pts, prm, labels_out=out, n=[npts] * k, on_device=True)
         if mode["record"]:      # ms_stage is the device time of each stage of the whole call (HIP events on the call's stream)
             with stat_lock:
-                for j in range(7):
+                for j in range(8):
                     stage_ms[j] += ctxs[g][0].result.ms_stage[j]
                 calls_done[0] += 1
                 frames_done[0] += k
@@ -219,21 +225,32 @@ def main():
         mode["host"] = False
 
     # the labels the timed region produced, against the oracle's committed hashes (tests/golden/oracle_golden_big.json, made in the
-    # build container by tools/make_golden_big.py): the last step's block holds the frames of seeds 1000 + 64 rank + i
+    # build container by tools/make_golden_big.py): the last step's block holds the frames of seeds 1000 + 64 rank + i.  Every frame of
+    # that block is checked on every rank; a mismatch voids the run (value null, exit code 1).
     parity = None
     try:
         import hashlib
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
-        blk = label_blocks[(args.steps - 1) % n_blocks]
+        blk = label_blocks[(args.steps - 1) % n_blocks].cpu().numpy()
         checked, bad = 0, []
-        for i in range(0, FPS, 8):
-            key = "config5_seed%d" % seeds[i]
-            if key in gold and npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD"):
+        if npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD"):
+            with ThreadPoolExecutor(16) as ex:
+                keys = ["config5_seed%d" % sd for sd in seeds]
+                have = [i for i in range(FPS) if keys[i] in gold]
+                digests = list(ex.map(lambda i: hashlib.sha256(blk[i].tobytes()).hexdigest(), have))
+            for i, dg in zip(have, digests):
                 checked += 1
-                if hashlib.sha256(blk[i].cpu().numpy().tobytes()).hexdigest() != gold[key]["labels_sha256"]:
+                if dg != gold[keys[i]]["labels_sha256"]:
                     bad.append(seeds[i])
-        if checked:
-            parity = {"frames_checked": checked, "mismatches": bad, "against": "SHA-256 of the oracle's per-point labels (tests/golden/oracle_golden_big.json)"}
+        if dist_on:
+            t = torch.tensor([checked, len(bad)], dtype=torch.int64, device=dev)
+            dist.all_reduce(t)
+            checked_all, bad_all = int(t[0].item()), int(t[1].item())
+        else:
+            checked_all, bad_all = checked, len(bad)
+        if checked_all:
+            parity = {"frames_checked": checked_all, "mismatches": bad, "mismatches_all_ranks": bad_all,
+                      "against": "SHA-256 of the oracle's per-point labels (tests/golden/oracle_golden_big.json), every frame of the last timed step's label block on every rank"}
     except Exception as e:      # noqa
         parity = {"error": repr(e)}
 
@@ -250,16 +267,23 @@ def main():
         value = world * total_frames * npts / elapsed / 1e6
         mean_stage = [m / max(1, calls_done[0]) for m in stage_ms]       # per batched launch sequence
         frames_per_launch = frames_done[0] / max(1, calls_done[0])
-        # The dominant KERNEL: the merge loop is ONE launch per call, so its launch duration is exactly the 'merge' stage
-        # measured live (HIP events on the call's stream).  The other stages are sequences of many launches of several kernels;
-        # the longest of their kernels (profiles/r2_kernel_stats.csv) is shorter than the merge launch.
-        dom = STAGES.index("merge")
+        # The dominant KERNEL, from what this run measured: the merge loop and the voxel normals are each ONE launch per call with their own
+        # pair of HIP events on the call's stream (f3ds_result.ms_stage[5] / [7]); the other stages are sequences of many launches of several
+        # kernels (their per-kernel split is in profiles/r3_kernel_stats*.csv) and are reported as stages below.
+        KERNELS = {5: ("k_batched<d_merge_cw_t<8,2>>", "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals>", "neighbours+normals", "d_normals")}
+        dom = max(KERNELS, key=lambda j: stage_ms[j])
         dom_ms = mean_stage[dom]
-        achieved = ALG_BYTES_PER_POINT * npts * frames_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        alg_launch = ALG_BYTES_PER_POINT * npts * frames_per_launch
+        achieved = alg_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = path_traffic = path_traffic_min = None
-        try:        # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")))
-            traffic = int(pm["kernels"]["d_merge_cw_t"]["hbm_bytes_per_frame"] * frames_per_launch)
+        pmc_file = None
+        for cand in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):      # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
+            if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+                pmc_file = cand
+                break
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            traffic = int(pm["kernels"][KERNELS[dom][2]]["hbm_bytes_per_frame"] * frames_per_launch)
             path_traffic = int(pm["whole_path_hbm_bytes_per_frame"])          # upper bound (every read request taken as 128 bytes)
             path_traffic_min = int(pm["whole_path_hbm_bytes_per_frame_min"])  # lower bound (64-byte requests in the kernels that gather)
         except Exception:
@@ -267,12 +291,20 @@ def main():
         whole = {"achieved": round(ALG_BYTES_PER_POINT * value * 1e6 / world / 1e9, 3), "unit": "GB/s", "frac": round(ALG_BYTES_PER_POINT * value * 1e6 / world / 1e9 / HBM_PEAK_GBS, 6),
                  "algorithmic_bytes_per_frame": ALG_BYTES_PER_POINT * npts, "traffic_per_frame": path_traffic, "traffic_per_frame_min": path_traffic_min,
                  "wasted_ratio": round(path_traffic / (ALG_BYTES_PER_POINT * npts), 2) if path_traffic else None,
-                 "traffic_source": "profiles/r2_pmc_hbm_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every launch of the path, units calibrated in profiles/r2_pmc_calibration.json"}
-        roofline = {"bound": "hbm", "kernel": "k_batched<d_merge_cw_t<8,2>>", "stage": "merge", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                 "traffic_source": "profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over every launch of the path (one call at a time), units calibrated in profiles/r2_pmc_calibration.json" % pmc_file}
+
+        def gbs(ms):
+            return round(alg_launch / (ms * 1e-3) / 1e9, 3) if ms > 0 else None
+        stages = {STAGES[i]: {"ms_per_call": round(mean_stage[i], 4), "achieved": gbs(mean_stage[i]), "frac": round(gbs(mean_stage[i]) / HBM_PEAK_GBS, 6) if mean_stage[i] > 0 else None}
+                  for i in range(7)}
+        stages["normals kernel (inside neighbours+normals)"] = {"ms_per_call": round(mean_stage[7], 4), "achieved": gbs(mean_stage[7]), "frac": round(gbs(mean_stage[7]) / HBM_PEAK_GBS, 6) if mean_stage[7] > 0 else None}
+        roofline = {"bound": "hbm", "kernel": KERNELS[dom][0], "stage": KERNELS[dom][1], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
-                    "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_POINT * npts * frames_per_launch),
+                    "algorithmic_bytes_per_launch": int(alg_launch),
+                    "dominant_by": "total launch time measured in this run: %s" % ", ".join("%s %.1f ms" % (KERNELS[j][2], stage_ms[j]) for j in KERNELS),
                     "whole_path": whole,
+                    "stages": stages,
                     "stage_ms_per_call": {STAGES[i]: round(mean_stage[i], 4) for i in range(7)}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -297,7 +329,23 @@ def main():
                    "note": "the port is faster than the reference would be: hash-set contains() instead of the O(E) scan, cached mean_color",
                    "host_cpus": os.cpu_count()}
             oh.close()
-        line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world,
+            # the fair multi-core number (SURVEY.md 8d iii): the 64-frame batch of the step, one frame per host core (the oracle is
+            # single-threaded like the reference; ctypes releases the GIL, so these are real threads on real cores)
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            nthr = max(1, min(FPS, ncores))
+            tp = time.perf_counter()
+            with ThreadPoolExecutor(nthr) as ex:
+                done = list(ex.map(lambda f: ora.segment(f, prm)[0], frames_host))
+            par_s = time.perf_counter() - tp
+            assert all(r == 0 for r in done)
+            cpu["frames_parallel"] = {"value": round(FPS * npts / par_s / 1e6, 4), "unit": "Mpoints/s", "cores": nthr, "host_cpus": ncores, "seconds": round(par_s, 2),
+                                      "sample": "the %d frames of one step, one frame per core on %d threads through oracle/libf3ds_oracle.so (label path only)" % (FPS, nthr)}
+        invalid = None
+        if parity and (parity.get("error") or parity.get("mismatches_all_ranks")):
+            invalid = "labels differ from the oracle's committed hashes" if not parity.get("error") else "label check failed: " + parity["error"]
+        if invalid:
+            value = None
+        line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3) if value is not None else None, "invalid": invalid, "unit": "Mpoints/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "step = batch of %d distinct synthetic %dx%d (%d-point) XYZRGBA frames per GPU (BASELINE config 5's batch, seeds 1000+64*rank..), "
@@ -322,6 +370,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+        if line.get("invalid"):
+            sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -130,6 +130,10 @@ def load_library(path=None):
     lib.f3ds_multi_device_of_frame.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_device_of_frame.restype = ctypes.c_int
     lib.f3ds_multi_segment.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.c_int, ctypes.POINTER(Params), ctypes.POINTER(vp), ctypes.POINTER(Result)]
     lib.f3ds_multi_segment.restype = ctypes.c_int
+    lib.f3ds_multi_submit.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.c_int, ctypes.POINTER(Params), ctypes.POINTER(vp), ctypes.POINTER(Result), ctypes.POINTER(ctypes.c_int)]
+    lib.f3ds_multi_submit.restype = ctypes.c_int
+    lib.f3ds_multi_collect.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_collect.restype = ctypes.c_int
+    lib.f3ds_multi_reserve.argtypes = [vp, sz]; lib.f3ds_multi_reserve.restype = ctypes.c_int
     lib.f3ds_multi_gathered_labels.argtypes = [vp]; lib.f3ds_multi_gathered_labels.restype = vp
     lib.f3ds_multi_last_error.restype = ctypes.c_char_p
     lib.f3ds_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_stream_create.restype = ctypes.c_int
@@ -488,8 +492,18 @@ class MultiGpu:
     def device_of_frame(self, frame):
         return self.lib.f3ds_multi_device_of_frame(self.handle, frame)
 
-    def segment(self, frames, params):
-        """frames: list of (N_i, 4) float32 arrays.  Returns (list of label arrays, list of Result)."""
+    def _error(self, rc):
+        return F3dsError(rc, self.lib.f3ds_strerror(rc).decode() + " " + self.lib.f3ds_multi_last_error().decode() + " " + self.lib.f3ds_last_hip_error().decode())
+
+    def reserve(self, max_points_per_frame):
+        """Allocate the label blocks for full batches of frames of up to that many points now, not inside the first batches."""
+        rc = self.lib.f3ds_multi_reserve(self.handle, int(max_points_per_frame))
+        if rc:
+            raise self._error(rc)
+
+    def submit(self, frames, params):
+        """Queue a batch (list of (N_i, 4) float32 arrays) and return a ticket: the GPUs compute it while the batch before it is
+        gathered and copied out.  At most two batches are in flight (F3dsError ERR_BUSY: collect the older one first)."""
         k = len(frames)
         vp = ctypes.c_void_p
         arrs = [np.ascontiguousarray(f, np.float32).reshape(-1, 4) for f in frames]
@@ -497,10 +511,29 @@ class MultiGpu:
         pp = (vp * max(k, 1))(*[vp(a.ctypes.data) for a in arrs]); lp = (vp * max(k, 1))(*[vp(o.ctypes.data) for o in out])
         cnt = (ctypes.c_size_t * max(k, 1))(*[len(a) for a in arrs])
         results = (Result * max(k, 1))()
-        rc = self.lib.f3ds_multi_segment(self.handle, pp, cnt, k, ctypes.byref(params), lp, results)
+        prm = params.copy()
+        t = ctypes.c_int(-1)
+        rc = self.lib.f3ds_multi_submit(self.handle, pp, cnt, k, ctypes.byref(prm), lp, results, ctypes.byref(t))
         if rc:
-            raise F3dsError(rc, self.lib.f3ds_strerror(rc).decode() + " " + self.lib.f3ds_multi_last_error().decode() + " " + self.lib.f3ds_last_hip_error().decode())
+            raise self._error(rc)
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[t.value] = (arrs, out, results, k)      # the buffers stay alive until the batch is collected
+        return t.value
+
+    def collect(self, ticket):
+        """Wait for a submitted batch.  Returns (list of label arrays, list of Result)."""
+        arrs, out, results, k = self._inflight.pop(ticket)
+        rc = self.lib.f3ds_multi_collect(self.handle, int(ticket))
+        if rc:
+            raise self._error(rc)
         return out, [results[i] for i in range(k)]
+
+    def segment(self, frames, params):
+        """frames: list of (N_i, 4) float32 arrays.  Returns (list of label arrays, list of Result)."""
+        if not frames:
+            return [], []
+        return self.collect(self.submit(frames, params))
 
 
 def segment_batch(ctxs, points, params, labels_out=None, n=None, on_device=False, raw_host=False):

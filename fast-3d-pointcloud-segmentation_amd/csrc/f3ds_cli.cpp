@@ -11,6 +11,7 @@
 // (:471, manageAllPerformances); every file is scored against its `label` field (:462-463).
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -84,7 +85,8 @@ int main(int argc, char** argv) {
                " --gpus <N>                     (with -t and --labels: files sharded over N GPUs, labels gathered on GPU 0 over RCCL) \n\t"
                " --dump <dir>                   (voxel centroids, supervoxel normals, adjacency graph, refined cloud as PCD: what the viewer shows) \n\t"
                " --stream <depth>               (with -t and --labels: files through the frame pipeline, <depth> in flight) \n\t"
-               " --refine <iterations>          (refineSupervoxels as main() does with 3, :369-375; with -o also <out.pcd>.refined) \n",
+               " --refine <iterations>          (refineSupervoxels as main() does with 3, :369-375; with -o also <out.pcd>.refined) \n\t"
+               " --bench <frames>               (no input files: <frames> synthetic 1M-point RGB-D frames through the path, with --gpus N sharded and pipelined; prints Mpoints/s) \n",
                argv[0]);
         return 1;
     }
@@ -108,7 +110,7 @@ int main(int argc, char** argv) {
     } else if (find_switch(argc, argv, "-p")) {
         parse(argc, argv, "-p", path);
         file_list.push_back(path);
-    } else {
+    } else if (!find_switch(argc, argv, "--bench")) {
         fprintf(stderr, "No input file or directory specified\n");
         return 1;
     }
@@ -187,9 +189,62 @@ int main(int argc, char** argv) {
     }
     int gpus = 0;
     if (find_switch(argc, argv, "--gpus")) parse(argc, argv, "--gpus", gpus);
+    if (find_switch(argc, argv, "--bench")) {
+        // Throughput of the path on synthetic frames (BASELINE.json config 2 / 5: 1000 x 1000 pinhole RGB-D frames, 3 % invalid depth,
+        // seeds 1000 ...), host buffers in, per-point labels in host buffers out.  With --gpus N: frame i -> GPU i mod N through the
+        // pipelined multi-GPU driver (chunks of 8 frames per GPU; chunk k+1 computes while chunk k's labels are gathered over RCCL
+        // and copied out).  The reference has no counterpart; bench.py is the harness the measured numbers of this repository come from.
+        int frames = 64;
+        parse(argc, argv, "--bench", frames);
+        if (frames <= 0 || !thresh_specified) { fprintf(stderr, "--bench <frames> needs a positive frame count and -t <threshold>\n"); return 1; }
+        const uint32_t W = 1000, H = 1000; const size_t npts = (size_t)W * H;
+        const int distinct = std::min(frames, 16);             // the frames cycle through 16 distinct seeds
+        std::vector<std::vector<P16>> pts((size_t)distinct, std::vector<P16>(npts));
+        for (int i = 0; i < distinct; ++i) if (f3ds_synth_frame(0, 1000u + (uint64_t)i, W, H, 30, pts[(size_t)i].data())) { fprintf(stderr, "f3ds_synth_frame failed\n"); return 1; }
+        const int G = gpus > 0 ? gpus : 1, per_device = 8, chunk = G * per_device;
+        f3ds_multi* mg = nullptr;
+        int rc = f3ds_multi_create(nullptr, G, per_device, &mg);
+        if (!rc) rc = f3ds_multi_reserve(mg, npts);
+        if (rc) { fprintf(stderr, "f3ds_multi_create(%d GPUs): %s %s %s\n", G, f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); return 1; }
+        std::vector<std::vector<uint32_t>> labels[2];
+        for (auto& l : labels) l.assign((size_t)chunk, std::vector<uint32_t>(npts));
+        auto run = [&](int total, double* seconds, f3ds_result* last) -> int {
+            const auto t0 = std::chrono::steady_clock::now();
+            int tickets[2] = {-1, -1}, sub = 0, col = 0;
+            const int nchunks = (total + chunk - 1) / chunk;
+            std::vector<f3ds_result> res[2]; res[0].resize((size_t)chunk); res[1].resize((size_t)chunk);
+            while (col < nchunks) {
+                if (sub < nchunks && sub - col < 2) {
+                    const int k0 = sub * chunk, k = std::min(chunk, total - k0), s = sub & 1;
+                    std::vector<const void*> pp; std::vector<size_t> cnt; std::vector<uint32_t*> lp;
+                    for (int i = 0; i < k; ++i) { pp.push_back(pts[(size_t)((k0 + i) % distinct)].data()); cnt.push_back(npts); lp.push_back(labels[s][(size_t)i].data()); }
+                    const int r = f3ds_multi_submit(mg, pp.data(), cnt.data(), k, &prm, lp.data(), res[s].data(), &tickets[s]);
+                    if (r) return r;
+                    sub++;
+                    continue;
+                }
+                const int r = f3ds_multi_collect(mg, tickets[col & 1]);
+                if (r) return r;
+                if (last) *last = res[col & 1][0];
+                col++;
+            }
+            *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            return F3DS_OK;
+        };
+        double sec = 0; f3ds_result r0;
+        rc = run(std::min(frames, 2 * chunk), &sec, nullptr);                  // untimed: scratch allocation, code objects
+        if (!rc) rc = run(frames, &sec, &r0);
+        if (rc) { fprintf(stderr, "--bench: %s %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); f3ds_multi_destroy(mg); return 1; }
+        printf("{\"bench\": \"supervoxel_clustering --bench\", \"frames\": %d, \"points_per_frame\": %zu, \"gpus\": %d, \"seconds\": %.4f, \"mpoints_per_s\": %.2f, "
+               "\"io\": \"host buffers in, labels in host buffers out\", \"voxels\": %u, \"supervoxels\": %u, \"merges\": %u, \"regions\": %u}\n",
+               frames, npts, G, sec, (double)frames * (double)npts / sec / 1e6, r0.n_voxels, r0.n_supervoxels, r0.n_merges, r0.n_regions);
+        f3ds_multi_destroy(mg);
+        return 0;
+    }
     if (gpus > 0) {
         // Multi-GPU batch mode (BASELINE.json config 5): file i -> GPU i mod N, one host thread per GPU, per-point labels
-        // gathered on GPU 0 in one RCCL exchange per chunk, then written.  No ground-truth sweep or scores here.
+        // gathered on GPU 0 in one RCCL exchange per chunk, then written; chunk k+1 is read and submitted while chunk k is still
+        // on the GPUs (f3ds_multi_submit / f3ds_multi_collect).  No ground-truth sweep or scores here.
         if (!thresh_specified || out_labels.empty() || remove_label) { fprintf(stderr, "--gpus needs -t <threshold> and --labels <file>, and does not take -r\n"); return 1; }
         const int per_device = 8;                                  // frames per GPU and chunk (config 5: 64 frames on 8 GPUs)
         f3ds_multi* mg = nullptr;
@@ -197,31 +252,46 @@ int main(int argc, char** argv) {
         if (rc) { fprintf(stderr, "f3ds_multi_create(%d GPUs): %s %s %s\n", gpus, f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); return 1; }
         int failed = 0;
         const size_t chunk = (size_t)gpus * per_device;
-        for (size_t k0 = 0; k0 < file_list.size() && !failed; k0 += chunk) {
-            const size_t k1 = std::min(file_list.size(), k0 + chunk);
-            std::vector<std::vector<P16>> pts(k1 - k0); std::vector<std::vector<uint32_t>> labels(k1 - k0);
-            std::vector<const void*> pp; std::vector<size_t> cnt; std::vector<uint32_t*> lp; std::vector<f3ds_result> res(k1 - k0);
-            for (size_t k = k0; k < k1; ++k) {
-                size_t n = 0;
-                if (f3ds_pcd_read(file_list[k].c_str(), nullptr, nullptr, 0, &n, nullptr, nullptr) == F3DS_OK) {
-                    pts[k - k0].resize(n);
-                    if (n && f3ds_pcd_read(file_list[k].c_str(), pts[k - k0].data(), nullptr, n, &n, nullptr, nullptr) != F3DS_OK) n = 0;
-                }
-                pts[k - k0].resize(n); labels[k - k0].resize(n);
-                pp.push_back(pts[k - k0].data()); cnt.push_back(n); lp.push_back(labels[k - k0].data());
-            }
-            rc = f3ds_multi_segment(mg, pp.data(), cnt.data(), (int)(k1 - k0), &prm, lp.data(), res.data());
-            if (rc) { fprintf(stderr, "f3ds_multi_segment: %s %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); failed = 1; break; }
-            for (size_t k = k0; k < k1; ++k) {
-                const std::string suffix = file_list.size() > 1 ? "." + std::filesystem::path(file_list[k]).stem().string() : "";
+        struct Chunk { std::vector<size_t> files; std::vector<std::vector<P16>> pts; std::vector<std::vector<uint32_t>> labels; std::vector<size_t> cnt; std::vector<f3ds_result> res; int ticket = -1; };
+        auto finish = [&](Chunk& c) {                           // wait for a submitted chunk and write its label files
+            if (c.ticket < 0) return;
+            const int r = f3ds_multi_collect(mg, c.ticket);
+            c.ticket = -1;
+            if (r) { fprintf(stderr, "f3ds_multi_segment: %s %s %s\n", f3ds_strerror(r), f3ds_last_hip_error(), f3ds_multi_last_error()); failed = 1; return; }
+            for (size_t i = 0; i < c.files.size(); ++i) {
+                const std::string& file = file_list[c.files[i]];
+                const std::string suffix = file_list.size() > 1 ? "." + std::filesystem::path(file).stem().string() : "";
                 FILE* f = fopen((out_labels + suffix).c_str(), "wb");
-                if (!f || fwrite(labels[k - k0].data(), 4, cnt[k - k0], f) != cnt[k - k0]) { fprintf(stderr, "writing %s failed\n", (out_labels + suffix).c_str()); failed = 1; }
+                if (!f || fwrite(c.labels[i].data(), 4, c.cnt[i], f) != c.cnt[i]) { fprintf(stderr, "writing %s failed\n", (out_labels + suffix).c_str()); failed = 1; }
                 if (f) fclose(f);
-                const f3ds_result& r = res[k - k0];
-                printf("%s: %llu points, %u voxels, %u supervoxels, %u merges -> %u regions (GPU %d of %d)\n", file_list[k].c_str(), (unsigned long long)r.n_points, r.n_voxels,
-                       r.n_supervoxels, r.n_merges, r.n_regions, f3ds_multi_device_of_frame(mg, (int)(k - k0)), gpus);
+                const f3ds_result& r2 = c.res[i];
+                printf("%s: %llu points, %u voxels, %u supervoxels, %u merges -> %u regions (GPU %d of %d)\n", file.c_str(), (unsigned long long)r2.n_points, r2.n_voxels,
+                       r2.n_supervoxels, r2.n_merges, r2.n_regions, f3ds_multi_device_of_frame(mg, (int)i), gpus);
             }
+        };
+        Chunk ring[2]; int turn = 0;
+        for (size_t k0 = 0; k0 < file_list.size(); k0 += chunk, turn ^= 1) {
+            Chunk& c = ring[turn];
+            finish(c);                                          // (the chunk submitted two rounds ago used these buffers)
+            const size_t k1 = std::min(file_list.size(), k0 + chunk);
+            c = Chunk();
+            for (size_t k = k0; k < k1; ++k) {
+                // a file that cannot be read fails the run (exit code 1) and is left out of the batch, as in the single-GPU path's error handling
+                size_t n = 0; std::vector<P16> p;
+                bool ok = f3ds_pcd_read(file_list[k].c_str(), nullptr, nullptr, 0, &n, nullptr, nullptr) == F3DS_OK;
+                if (ok) { p.resize(n); if (n && f3ds_pcd_read(file_list[k].c_str(), p.data(), nullptr, n, &n, nullptr, nullptr) != F3DS_OK) ok = false; }
+                if (!ok) { fprintf(stderr, "%s: cannot read PCD file\n", file_list[k].c_str()); failed = 1; continue; }
+                p.resize(n);
+                c.files.push_back(k); c.pts.push_back(std::move(p)); c.labels.emplace_back(n); c.cnt.push_back(n);
+            }
+            if (c.files.empty()) continue;
+            c.res.resize(c.files.size());
+            std::vector<const void*> pp; std::vector<uint32_t*> lp;
+            for (size_t i = 0; i < c.files.size(); ++i) { pp.push_back(c.pts[i].data()); lp.push_back(c.labels[i].data()); }
+            rc = f3ds_multi_submit(mg, pp.data(), c.cnt.data(), (int)c.files.size(), &prm, lp.data(), c.res.data(), &c.ticket);
+            if (rc) { fprintf(stderr, "f3ds_multi_submit: %s %s %s\n", f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); failed = 1; break; }
         }
+        finish(ring[turn]); finish(ring[turn ^ 1]);
         f3ds_multi_destroy(mg);
         return failed;
     }

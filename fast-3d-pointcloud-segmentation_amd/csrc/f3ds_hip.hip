@@ -10,7 +10,7 @@
 //   4 summaries  d_sv_fill (payload rows + ordered leaf sums), d_edges, radix sort, d_edge_init,
 //                d_edge_deltas, d_lambda / d_cdf_*, d_edge_weights
 //   5 merge      d_merge_cw_t<2 or 8 waves, LDS residency> (one persistent workgroup per frame), d_merge (global memory)
-//   6 labels     d_roots (+scan), d_point_labels
+//   6 labels     d_relabel (union-find relabel in LDS + per-point label write; d_region_ids + d_point_labels beyond 12 k supervoxels)
 // Every frame RECORDS its kernel calls; flush() zips the records of a batch into one dispatch per kernel (grid.y = frame).
 //
 // Layout in HBM: points stay as the caller's 16-byte records (one global_load_dwordx4 per lane);
@@ -102,7 +102,7 @@ struct f3ds_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[9] = {};
+    hipEvent_t ev[11] = {};            // 0..7 stage boundaries, 9 / 10 around the d_normals launch
     DevCounters* d_dc = nullptr;
     DevCounters* h_dc = nullptr;       // pinned
     GridInfo* d_grid = nullptr;
@@ -111,8 +111,10 @@ struct f3ds_ctx {
     // recorded, not yet launched kernel calls of this frame
     std::vector<Cmd> cmds;
     std::vector<unsigned char> blob;
+    std::vector<uintptr_t> pend;       // device addresses the recorded calls refer to (pointer arguments; every aligned word of struct arguments)
     // pinned + device staging for the packed arguments of a batch (owned by the batch's first context)
-    unsigned char* h_args = nullptr; unsigned char* d_args = nullptr; size_t args_cap = 0;
+    unsigned char* h_args[2] = {nullptr, nullptr}; unsigned char* d_args[2] = {nullptr, nullptr}; size_t args_cap = 0;      // two arenas, used in turn: a flush never waits for the stream
+    hipEvent_t ev_args[2] = {nullptr, nullptr}; bool args_used[2] = {false, false}; int args_flip = 0;
     DevCounters* d_dcblk = nullptr; DevCounters* h_dcblk = nullptr; size_t dcblk_cap = 0;      // the batch's counters, one slot per frame
     // frame state
     bool have_frame = false;
@@ -131,6 +133,7 @@ struct f3ds_ctx {
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
     uint32_t edge_mult = 32;           // adjacency list room per seed (S0 * edge_mult + 1024), grown on demand
+    bool relabel_lds = true;           // stage 6 as one kernel (the region-id table fits LDS for every frame of the batch)
     int refined_itr = -1;              // >= 0: the r_* buffers hold the state after that many refinement iterations of this frame
     int idxbits = -1;                  // >= 0: the sorted point keys carry the point index in their low bits
     uint32_t* user_labels = nullptr;   // device label buffer of the caller for the current call (else c->labels + copy)
@@ -143,21 +146,27 @@ struct f3ds_ctx {
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
     Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
-    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rflags, pool, rstart, rnleaf, rcap, rincl;
+    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, rincl;
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
 
 namespace {
 
-// A recorded, not yet flushed kernel call holds raw device pointers in its argument blob: a buffer such a call refers to
-// must not be freed and reallocated before the flush (the dispatch would write into freed memory).  Checked on every regrow.
+// A recorded, not yet flushed kernel call holds raw device pointers: a buffer such a call refers to must not be freed and
+// reallocated before the flush (the dispatch would write into freed memory).  rec<>() notes the address of every pointer-typed
+// argument (and, for the few struct arguments -- SweepFrame, MergeDev, MergeLds --, every 8-byte word of the struct, which is
+// where their pointer members sit); scalar arguments are never mistaken for addresses.  Checked on every regrow.
 bool referenced_by_pending_calls(const f3ds_ctx* c, const Buf& b) {
     const uintptr_t lo = (uintptr_t)b.p, hi = lo + b.cap;
-    for (size_t off = 0; off + 8 <= c->blob.size(); off += 8) {
-        uint64_t w; memcpy(&w, c->blob.data() + off, 8);
-        if (w >= lo && w < hi) return true;
-    }
+    for (const uintptr_t w : c->pend) if (w >= lo && w < hi) return true;
     return false;
+}
+template <class A> inline void note_arg(f3ds_ctx* c, const A& a) {
+    if constexpr (std::is_pointer<A>::value) { if (a) c->pend.push_back((uintptr_t)a); }
+    else if constexpr (std::is_class<A>::value) {
+        static_assert(std::is_trivially_copyable<A>::value, "kernel arguments must be plain data");
+        for (size_t off = 0; off + 8 <= sizeof(A); off += 8) { uintptr_t w; memcpy(&w, reinterpret_cast<const unsigned char*>(&a) + off, 8); if (w) c->pend.push_back(w); }
+    }
 }
 // Scratch is grow-only per context, and sized by the largest frame ANY context of the device has seen: g_scratch_hwm holds,
 // per buffer slot, the largest request so far.  A context that has to grow a buffer -- or meets a request below the mark
@@ -178,23 +187,44 @@ int ensure(f3ds_ctx* c, Buf& b, size_t count, T** out) {
         while (seen < bytes && !hwm.compare_exchange_weak(seen, bytes, std::memory_order_relaxed)) {}
         if (seen > target && seen <= 4 * bytes) target = seen;      // (a frame of another scale altogether does not size this one)
     }
-    if (b.cap < target) {
-        const bool pinned = b.p && !c->cmds.empty() && referenced_by_pending_calls(c, b);
-        if (pinned && b.cap < bytes) {
+    // ENSURE is an idempotent getter while the buffer covers the request: contents are only ever discarded when the request does not
+    // fit (the caller is about to overwrite the buffer anyway).  The device-wide mark sizes such a regrow; buffers that are merely
+    // below the mark are brought up to it by pregrow_scratch() at the start of a segment call, when no buffer holds frame state.
+    if (b.cap < bytes) {
+        if (b.p && !c->cmds.empty() && referenced_by_pending_calls(c, b)) {
             fprintf(stderr, "f3ds: internal error: regrowing a buffer that a recorded kernel call refers to\n");
             return F3DS_ERR_LOGIC;
         }
-        if (!pinned) {
-            g_scratch_allocs.fetch_add(1, std::memory_order_relaxed);
-            static const bool trace = getenv("F3DS_TRACE_ALLOC") != nullptr;
-            if (trace && b.p) fprintf(stderr, "f3ds: regrow slot %td: cap %zu, request %zu, mark %zu, pending calls %zu\n", slot, b.cap, bytes, target, c->cmds.size());
-            if (b.p) { HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
-            size_t want = target + target / 4 + 64;
-            HIPCHECK(hipMalloc(&b.p, want));
-            b.cap = want;
-        }
+        g_scratch_allocs.fetch_add(1, std::memory_order_relaxed);
+        static const bool trace = getenv("F3DS_TRACE_ALLOC") != nullptr;
+        if (trace && b.p) fprintf(stderr, "f3ds: regrow slot %td: cap %zu, request %zu, mark %zu, pending calls %zu\n", slot, b.cap, bytes, target, c->cmds.size());
+        if (b.p) { HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        size_t want = target + target / 4 + 64;
+        HIPCHECK(hipMalloc(&b.p, want));
+        b.cap = want;
     }
     *out = reinterpret_cast<T*>(b.p);
+    return F3DS_OK;
+}
+// Start of a segment call: nothing is recorded and no buffer holds state of a frame that will be read again (the call starts a new
+// frame), so this is the one moment a context may trade a buffer for a larger one without losing anything.  Every allocated buffer
+// that is below the device-wide mark of its slot (within 4x) goes to the mark: a pool of contexts fed with frames of varying size
+// stops allocating once every context has been used twice (hipFree waits for the whole device: a regrow in steady state stalls
+// every batch in flight).
+int pregrow_scratch(f3ds_ctx* c) {
+    Buf* bufs = &c->pts;
+    const size_t nb = (reinterpret_cast<char*>(&c->rincl) - reinterpret_cast<char*>(&c->pts)) / sizeof(Buf) + 1;
+    for (size_t i = 0; i < nb && i < 160; ++i) {
+        Buf& b = bufs[i];
+        if (!b.p) continue;
+        const size_t mark = g_scratch_hwm[c->device & 15][i].load(std::memory_order_relaxed);
+        if (b.cap >= mark || mark > 4 * b.cap) continue;
+        g_scratch_allocs.fetch_add(1, std::memory_order_relaxed);
+        HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0;
+        const size_t want = mark + mark / 4 + 64;
+        HIPCHECK(hipMalloc(&b.p, want));
+        b.cap = want;
+    }
     return F3DS_OK;
 }
 #define ENSURE(buf, T, count, ptr) do { int rc_ = ensure<T>(c, buf, (size_t)(count), &ptr); if (rc_) return rc_; } while (0)
@@ -232,6 +262,7 @@ void rec(f3ds_ctx* c, uint32_t gx, uint32_t lds, As... as) {
     Pack p;
     memset(&p, 0, sizeof p);
     fill_pack(p, as...);
+    (note_arg(c, as), ...);
     Cmd cmd; cmd.fn = &launch_fn<K>; cmd.gx = gx; cmd.lds = lds; cmd.bytes = (uint32_t)sizeof(Pack); cmd.off = (uint32_t)c->blob.size();
     c->blob.resize(c->blob.size() + sizeof(Pack));
     memcpy(c->blob.data() + cmd.off, &p, sizeof(Pack));
@@ -275,28 +306,39 @@ int flush(Batch& b) {
     f3ds_ctx* o = b.owner;
     if (o->args_cap < total) {
         HIPCHECK(hipStreamSynchronize(b.st));
-        if (o->h_args) HIPCHECK(hipHostFree(o->h_args));
-        if (o->d_args) HIPCHECK(hipFree(o->d_args));
+        for (int k = 0; k < 2; ++k) {
+            if (o->h_args[k]) HIPCHECK(hipHostFree(o->h_args[k]));
+            if (o->d_args[k]) HIPCHECK(hipFree(o->d_args[k]));
+            o->h_args[k] = o->d_args[k] = nullptr; o->args_used[k] = false;
+        }
         o->args_cap = total * 2;
-        HIPCHECK(hipHostMalloc((void**)&o->h_args, o->args_cap, hipHostMallocDefault));
-        HIPCHECK(hipMalloc((void**)&o->d_args, o->args_cap));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHECK(hipHostMalloc((void**)&o->h_args[k], o->args_cap, hipHostMallocDefault));
+            HIPCHECK(hipMalloc((void**)&o->d_args[k], o->args_cap));
+            if (!o->ev_args[k]) HIPCHECK(hipEventCreateWithFlags(&o->ev_args[k], hipEventDisableTiming));
+        }
     }
-    // the pinned arena may still feed an earlier, not yet completed copy
-    { const double t0 = now_ms(); HIPCHECK(hipStreamSynchronize(b.st)); g_t_wait += now_ms() - t0; }
+    // The argument blocks of a flush travel pinned arena -> device arena -> kernels.  Two arena pairs are used in turn and an event marks the
+    // end of the last dispatch that reads a pair, so the host packs and launches stage k+1 while stage k still runs: the only wait here is
+    // for the flush before the previous one, which is long over (round 2 synchronised the stream at every flush).
+    const int fl = o->args_flip; o->args_flip ^= 1;
+    if (o->args_used[fl]) { const double t0 = now_ms(); HIPCHECK(hipEventSynchronize(o->ev_args[fl])); g_t_wait += now_ms() - t0; }
+    unsigned char* const h_args = o->h_args[fl]; unsigned char* const d_args = o->d_args[fl];
     const double tl0 = now_ms();
     for (size_t j = 0; j < ncmd; ++j)
         for (uint32_t i = 0; i < nf; ++i) {
             const Cmd& cm = b.fr[i]->cmds[j];
             if (cm.fn != b.fr[0]->cmds[j].fn) return F3DS_ERR_UNSUPPORTED;
-            memcpy(o->h_args + off[j] + (size_t)i * cm.bytes, b.fr[i]->blob.data() + cm.off, cm.bytes);
+            memcpy(h_args + off[j] + (size_t)i * cm.bytes, b.fr[i]->blob.data() + cm.off, cm.bytes);
         }
-    HIPCHECK(hipMemcpyAsync(o->d_args, o->h_args, total, hipMemcpyHostToDevice, b.st));
+    HIPCHECK(hipMemcpyAsync(d_args, h_args, total, hipMemcpyHostToDevice, b.st));
     for (size_t j = 0; j < ncmd; ++j) {
         uint32_t gx = 1, lds = 0;
         for (uint32_t i = 0; i < nf; ++i) { const Cmd& cm = b.fr[i]->cmds[j]; if (cm.gx > gx) gx = cm.gx; if (cm.lds > lds) lds = cm.lds; }
-        HIPCHECK(b.fr[0]->cmds[j].fn(gx, nf, lds, b.st, o->d_args + off[j]));
+        HIPCHECK(b.fr[0]->cmds[j].fn(gx, nf, lds, b.st, d_args + off[j]));
     }
-    for (f3ds_ctx* c : b.fr) { c->cmds.clear(); c->blob.clear(); }
+    HIPCHECK(hipEventRecord(o->ev_args[fl], b.st)); o->args_used[fl] = true;
+    for (f3ds_ctx* c : b.fr) { c->cmds.clear(); c->blob.clear(); c->pend.clear(); }
     g_t_launch += now_ms() - tl0;
     return F3DS_OK;
 }
@@ -400,7 +442,7 @@ int seg_sort(f3ds_ctx* c, int sort_bits, int idxbits) {      // idxbits >= 0: (c
 // stage 0c + 1 + 2a: voxel sums, neighbour tables, normals, seed grid growth
 int seg_voxels(f3ds_ctx* c) {
     const uint32_t V = c->V, n = c->n;
-    uint32_t *vkey, *vcount, *hvals; float *vf, *boxes; int *nbr, *nbrT; uint64_t* hkeys;
+    uint32_t *vkey, *vcount, *hvals; float *vf; int *nbr, *nbrT; uint64_t* hkeys;
     const uint32_t hcap = pow2_ge((size_t)V * 2 + 16);
     c->hmask = hcap - 1;
     ENSURE(c->vkey, uint32_t, (size_t)V * 3, vkey); ENSURE(c->vcount, uint32_t, V, vcount); ENSURE(c->vf, float, (size_t)V * 12, vf);
@@ -416,7 +458,18 @@ int seg_voxels(f3ds_ctx* c) {
                                   (const DevCounters*)c->d_dc, c->fa, (const GridInfo*)c->d_grid, vkey, vcount, vf, hkeys, hvals, c->hmask, (int*)c->pt_voxel.p);
     rec<d_neighbors>(c, grid_wide((size_t)V * 27, 256), 0u, (const uint32_t*)vkey, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                      c->hmask, nbr, nbrT);
-    rec<d_normals>(c, (V + NT_TILE - 1) / NT_TILE, 0u, vf, (const int*)nbr, (const DevCounters*)c->d_dc);
+    return F3DS_OK;
+}
+// stage 1b: voxel normals -- ONE launch per batch call, bracketed by its own pair of events (f3ds_result.ms_stage[7]: besides the merge
+// loop the only kernel of the path whose launch duration is measured live, bench.py's roofline picks the longer of the two)
+int seg_normals(f3ds_ctx* c) {
+    rec<d_normals>(c, (c->V + NT_TILE - 1) / NT_TILE, 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc);
+    return F3DS_OK;
+}
+// stage 2a: seed grid growth
+int seg_seed_grid(f3ds_ctx* c) {
+    const uint32_t V = c->V;
+    float* boxes; const float* vf = (const float*)c->vf.p;
     const uint32_t nchunks = (V + SEED_CHUNK - 1) / SEED_CHUNK;
     ENSURE(c->boxes, float, (size_t)nchunks * 6, boxes);
     rec<d_chunkbox>(c, nchunks, 0u, (const float*)vf, (const DevCounters*)c->d_dc, boxes);
@@ -673,18 +726,24 @@ int seg_merge(f3ds_ctx* c) {
     }
     return F3DS_OK;
 }
-// stage 6: region ids (ascending surviving label) and per-point labels
+// stage 6: region ids (ascending surviving label) and per-point labels: one kernel (rank table in LDS), or two when some frame of
+// the batch has more supervoxels than the table holds (c->relabel_lds, decided for the whole batch in run_cluster)
 int seg_labels(f3ds_ctx* c) {
     const uint32_t S0 = c->S0, n = c->n;
     const MergeDev& m = c->mdev;
-    uint32_t *root, *rflags, *rincl, *d_labels;
-    ENSURE(c->root, uint32_t, S0 + 1, root); ENSURE(c->rflags, uint32_t, S0 + 1, rflags); ENSURE(c->rincl, uint32_t, S0 + 1, rincl);
+    uint32_t *root, *rincl, *d_labels;
+    ENSURE(c->root, uint32_t, S0 + 1, root); ENSURE(c->rincl, uint32_t, S0 + 1, rincl);
     if (c->user_labels) d_labels = c->user_labels;      // a device output buffer is written in place
     else ENSURE(c->labels, uint32_t, n, d_labels);
-    rec<d_roots>(c, grid_for(S0 + 1, 256), 0u, S0, (const uint32_t*)m.parent, (const unsigned char*)m.ralive, root, rflags);
-    int rc = scan_u32(c, rflags, rincl, S0 + 1);
-    if (rc) return rc;
-    rec<d_point_labels>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)c->owner0.p, (const uint32_t*)root, (const uint32_t*)rincl, S0, d_labels, c->d_dc);
+    if (c->relabel_lds) {
+        // (every workgroup builds the table: a lone frame does not get more workgroups than it has 4096-point slices)
+        const uint32_t gx = std::min(grid_for(n, 256), grid_wide(n, 4096));
+        rec<d_relabel>(c, gx, (S0 + 1u) * 4u, n, (const int*)c->pt_voxel.p, (const uint32_t*)c->owner0.p, S0, (const uint32_t*)m.parent, (const unsigned char*)m.ralive, root, rincl, d_labels, c->d_dc);
+    } else {
+        uint32_t* rank; ENSURE(c->rrank, uint32_t, S0 + 1, rank);
+        rec<d_region_ids>(c, 1u, 0u, S0, (const uint32_t*)m.parent, (const unsigned char*)m.ralive, rank, root, rincl, c->d_dc);
+        rec<d_point_labels>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)c->owner0.p, (const uint32_t*)rank, d_labels);
+    }
     return F3DS_OK;
 }
 
@@ -720,31 +779,6 @@ struct BatchStreamLease {
     ~BatchStreamLease() { if (slot >= 0) { std::lock_guard<std::mutex> lk(g_batch_streams[dev].m); g_batch_streams[dev].busy[slot] = false; } }
 };
 
-// EXPERIMENT (F3DS_MERGE_CUS=<n>): the merge dispatch of a batch goes to a stream whose CU mask holds every (256/n)-th compute unit, so that the merge
-// workgroups of all calls in flight pack onto n CUs (as many per CU as LDS and registers allow) and leave the others to the wide kernels.
-struct MergeStreamPool { std::mutex m; hipStream_t s[8] = {}; bool busy[8] = {}; };
-MergeStreamPool g_merge_streams[16];
-const int g_merge_cus = [] { const char* e = getenv("F3DS_MERGE_CUS"); return e ? atoi(e) : 0; }();
-struct MergeStreamLease {
-    int dev = -1, slot = -1;
-    hipStream_t acquire(int device) {
-        if (g_merge_cus <= 0) return nullptr;
-        MergeStreamPool& p = g_merge_streams[device & 15];
-        std::lock_guard<std::mutex> lk(p.m);
-        if (!p.s[0]) {
-            uint32_t mask[8] = {};
-            const char* e = getenv("F3DS_MERGE_CU_STRIDE"); const int stride = e ? atoi(e) : 256 / g_merge_cus;
-            const char* e0 = getenv("F3DS_MERGE_CU_FIRST"); const int first = e0 ? atoi(e0) : 0;
-            int n = 0;
-            for (int cu = first; cu < 256 && n < g_merge_cus; cu += (stride > 0 ? stride : 1)) { mask[cu >> 5] |= 1u << (cu & 31); n++; }
-            for (int i = 0; i < 8; ++i) if (hipExtStreamCreateWithCUMask(&p.s[i], 8, mask) != hipSuccess) { p.s[i] = nullptr; return nullptr; }
-        }
-        for (int i = 0; i < 8; ++i) if (!p.busy[i] && p.s[i]) { p.busy[i] = true; dev = device & 15; slot = i; return p.s[i]; }
-        return nullptr;
-    }
-    ~MergeStreamLease() { if (slot >= 0) { std::lock_guard<std::mutex> lk(g_merge_streams[dev].m); g_merge_streams[dev].busy[slot] = false; } }
-};
-
 // run `fn` (a per-frame recorder) on every live frame; a failing frame fails the batch
 template <class F>
 int for_frames(Batch& b, F&& fn) {
@@ -760,21 +794,15 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     int rc = for_frames(b, [&](f3ds_ctx* c) { return seg_cluster_front(c, prm, kind); });
     if (rc || (rc = flush(b))) return rc;
     stage_mark(b, 5);
-    {
-        MergeStreamLease ml;
-        hipStream_t ms = all_lds ? ml.acquire(b.fr[0]->device) : nullptr;
-        if (ms) {
-            HIPCHECK(hipStreamSynchronize(b.st));
-            hipStream_t keep = b.st; b.st = ms;
-            rc = for_frames(b, seg_merge); if (!rc) rc = flush(b);
-            const hipError_t se = rc ? hipSuccess : hipStreamSynchronize(ms);
-            b.st = keep;      // (restored on every path)
-            if (rc) return rc;
-            HIPCHECK(se);
-        } else if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
-    }
+    if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
     stage_mark(b, 6);
     for (size_t i = 0; i < b.fr.size(); ++i) b.fr[i]->user_labels = (labels_on_device && labels_of) ? labels_of[index_of[i]] : nullptr;
+    {
+        const uint32_t cap = getenv("F3DS_RELABEL_LDS_CAP") ? (uint32_t)atol(getenv("F3DS_RELABEL_LDS_CAP")) : RL_LDS_CAP;      // (tests: 0 forces the two-kernel form)
+        bool fits = true;
+        for (f3ds_ctx* c : b.fr) if (c->S0 + 1u > cap) fits = false;
+        for (f3ds_ctx* c : b.fr) c->relabel_lds = fits;
+    }
     if ((rc = for_frames(b, seg_labels)) || (rc = flush(b))) return rc;
     stage_mark(b, 7);
     for (size_t i = 0; i < b.fr.size(); ++i) {
@@ -875,10 +903,9 @@ void f3ds_destroy(f3ds_ctx* c) {
     if (c->d_grid) (void)hipFree(c->d_grid);
     if (c->h_grid) (void)hipHostFree(c->h_grid);
     if (c->d_sgrid) (void)hipFree(c->d_sgrid);
-    if (c->h_args) (void)hipHostFree(c->h_args);
+    for (int k = 0; k < 2; ++k) { if (c->h_args[k]) (void)hipHostFree(c->h_args[k]); if (c->d_args[k]) (void)hipFree(c->d_args[k]); if (c->ev_args[k]) (void)hipEventDestroy(c->ev_args[k]); }
     if (c->d_dcblk) (void)hipFree(c->d_dcblk);
     if (c->h_dcblk) (void)hipHostFree(c->h_dcblk);
-    if (c->d_args) (void)hipFree(c->d_args);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -919,8 +946,9 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     stage_mark(b, 0);
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
-        c->cmds.clear(); c->blob.clear();
+        c->cmds.clear(); c->blob.clear(); c->pend.clear();
         c->have_frame = false; c->live = true; c->rc = 0; c->refined_itr = -1;
+        { const int prc = pregrow_scratch(c); if (prc) return prc; }
         c->prm = *prm; c->n = (uint32_t)counts[i]; c->V = c->C = c->S0 = c->E = 0;
         memset(&c->res, 0, sizeof c->res);
         c->res.n_points = c->n; c->res.sweeps = sweeps;
@@ -964,8 +992,11 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = drop_dead([](f3ds_ctx* c) { return c->V == 0; }))) return rc;
     stage_mark(b, 1);
     // ---- stage 1 + 2: neighbours, normals, seeds
-    if ((rc = for_frames(b, seg_voxels))) return rc;
-    if ((rc = flush(b))) return rc;
+    if ((rc = for_frames(b, seg_voxels)) || (rc = flush(b))) return rc;
+    stage_mark(b, 9);
+    if ((rc = for_frames(b, seg_normals)) || (rc = flush(b))) return rc;
+    stage_mark(b, 10);
+    if ((rc = for_frames(b, seg_seed_grid)) || (rc = flush(b))) return rc;
     stage_mark(b, 2);
     if ((rc = flush_sync(b))) return rc;
     int maxsd = 0;
@@ -1008,6 +1039,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     float stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // device time of each stage of the whole batch (HIP events on the batch's stream)
     for (int k = 0; k < 7; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[k], b.owner->ev[k + 1]) == hipSuccess) stage[k] = ms; }
+    if (!b.fr.empty()) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[9], b.owner->ev[10]) == hipSuccess) stage[7] = ms; }      // the d_normals launch (inside stage 1)
     const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("F3DS_HOST_PROF")) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic; stages %.0f %.0f %.0f %.0f %.0f %.0f %.0f ms; %llu scratch allocations so far\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch, stage[0], stage[1], stage[2], stage[3], stage[4], stage[5], stage[6], g_scratch_allocs.load());
     for (int i = 0; i < nctx; ++i) {
@@ -1025,7 +1057,7 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
-    c->cmds.clear(); c->blob.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear();
     c->h_dc->error = 0;
     HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), c->stream));
     stage_mark(b, 4);
@@ -1119,7 +1151,7 @@ extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
-    c->cmds.clear(); c->blob.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear();
     c->refined_itr = -1;
     const uint32_t V = c->V, S0 = c->S0;
     float *r_vf, *r_hc; uint32_t *r_owner, *r_hcount, *L; int *r_gvox, *seed; unsigned char* r_gact;
@@ -1331,7 +1363,7 @@ int eval_truth(f3ds_ctx* c, const uint32_t* truth_point_labels) {
     HIPCHECK(hipMemcpyAsync(tp, truth_point_labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemsetAsync(tsum, 0, (size_t)V * 12, c->stream));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
-    c->cmds.clear(); c->blob.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear();
     rec<d_truth_accum>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)tp, (const uint32_t*)lut, tsum);
     rec<d_truth_color>(c, grid_for(V, 256), 0u, V, (const uint32_t*)tsum, (const uint32_t*)c->vcount.p, tcol);
     int rc = flush_sync(b);
@@ -1359,7 +1391,7 @@ int eval_scores(f3ds_ctx* c, const uint32_t* d_root, const uint32_t* d_incl, uin
     HIPCHECK(hipMemsetAsync(tab, 0, (size_t)K * M * 4, c->stream));
     HIPCHECK(hipMemsetAsync(ssz, 0, (size_t)K * 4, c->stream));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
-    c->cmds.clear(); c->blob.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear();
     rec<d_contingency>(c, grid_for(V, 256), 0u, V, M, (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
     rec<d_contingency_ghost>(c, grid_for(c->S0, 256), 0u, c->S0, M, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p,
                              (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);

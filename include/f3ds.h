@@ -90,7 +90,8 @@ typedef struct f3ds_result {
     float ms_total;               /* wall time of the call, host clock                   */
     float ms_stage[8];            /* device time per stage (HIP events): 0 voxelise,
                                      1 neighbours+normals, 2 seeds, 3 sweeps, 4 supervoxel
-                                     summaries+edges, 5 merge, 6 labels, 7 reserved      */
+                                     summaries+edges, 5 merge, 6 labels; 7 = the voxel-normal
+                                     kernel's launch alone (part of stage 1)             */
 } f3ds_result;
 
 typedef struct f3ds_ctx f3ds_ctx;
@@ -266,8 +267,19 @@ int f3ds_multi_device_of_frame(const f3ds_multi* m, int frame);
  * results may be NULL.  F3DS_ERR_CAPACITY when n_frames > n_devices * max_frames_per_device. */
 int f3ds_multi_segment(f3ds_multi* m, const void* const* points, const size_t* counts, int n_frames, const f3ds_params* params,
                        uint32_t* const* point_labels, f3ds_result* results);
-/* the gathered label block on devices[0] after f3ds_multi_segment (device pointer): device d's frames, in frame order, start
- * at the sum of the point counts of the devices before d */
+/* Pipelined form: f3ds_multi_submit queues a batch (same arguments; the arrays are copied, the point and label buffers must stay
+ * valid until the batch is collected) and returns a ticket; the GPUs compute batch k+1 while batch k's labels are gathered on
+ * devices[0] and copied to the host buffers.  At most two batches are in flight: F3DS_ERR_BUSY when the batch submitted two
+ * calls ago has not been collected yet.  f3ds_multi_collect waits for a batch and returns its status (once per ticket).
+ * f3ds_multi_segment == submit + collect. */
+int f3ds_multi_submit(f3ds_multi* m, const void* const* points, const size_t* counts, int n_frames, const f3ds_params* params,
+                      uint32_t* const* point_labels, f3ds_result* results, int* ticket);
+int f3ds_multi_collect(f3ds_multi* m, int ticket);
+/* allocate the label blocks for batches of max_frames_per_device frames of up to max_points_per_frame points now (otherwise they
+ * grow inside the first batches); F3DS_ERR_BUSY while a batch is in flight */
+int f3ds_multi_reserve(f3ds_multi* m, size_t max_points_per_frame);
+/* the gathered label block on devices[0] of the batch gathered last (device pointer): device d's frames, in frame order, start
+ * at the sum of the point counts of the devices before d; valid until the batch after the next one is submitted */
 const uint32_t* f3ds_multi_gathered_labels(const f3ds_multi* m);
 const char* f3ds_multi_last_error(void);
 

@@ -135,5 +135,8 @@ def test_multi_gpu_driver_argument_checks_need_no_gpu(P):
     prm = P.default_params()
     assert lib.f3ds_multi_segment(None, None, None, 0, ctypes.byref(prm), None, None) == P.ERR_ARG
     assert lib.f3ds_multi_gathered_labels(None) is None
+    t = ctypes.c_int(7)
+    assert lib.f3ds_multi_submit(None, None, None, 0, ctypes.byref(prm), None, None, ctypes.byref(t)) == P.ERR_ARG      # the pipelined form
+    assert lib.f3ds_multi_collect(None, 0) == P.ERR_ARG and lib.f3ds_multi_reserve(None, 1000) == P.ERR_ARG
     lib.f3ds_multi_destroy(None)
     assert isinstance(lib.f3ds_multi_last_error(), bytes)

@@ -48,8 +48,10 @@ def test_nyu_scale_frame_matches_oracle(P, oracle, gpu_ctx):
     prm = P.launch_params()
     labels = gpu_ctx.segment(pts, prm)
     _invariants(P, pts, labels, gpu_ctx.result)
-    rc, olab, ores, _ = oracle.segment(pts, prm)
+    rc, olab, ores, oh = oracle.segment(pts, prm)
     assert rc == 0 and np.array_equal(labels, olab)
+    problems = [m for m in (first_mismatch(w, oh.get(w), gpu_ctx.debug(w)) for w in ALL_DEBUG) if m]      # all 20 intermediate arrays
+    assert not problems, "\n".join(problems)
 
 
 def test_20m_scene_properties(P, gpu_ctx):
