@@ -233,7 +233,7 @@ def main():
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
         blk = label_blocks[(args.steps - 1) % n_blocks].cpu().numpy()
         checked, bad = 0, []
-        if npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD"):
+        if npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD") and not os.environ.get("F3DS_FAKE_MERGE"):      # (development what-if runs change the labels)
             with ThreadPoolExecutor(16) as ex:
                 keys = ["config5_seed%d" % sd for sd in seeds]
                 have = [i for i in range(FPS) if keys[i] in gold]
@@ -356,6 +356,7 @@ def main():
                            "parallelism": ("%d ranks, one per GPU, every rank its own frames" % world) if world > 1 else "1 GPU",
                            "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
+                "what_if": {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_FAKE_MERGE") if os.environ.get(k)} or None,
                 "value_host_io": host_io, "labels_checked": parity, "single_frame_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
     for grp in ctxs:
         for c in grp:

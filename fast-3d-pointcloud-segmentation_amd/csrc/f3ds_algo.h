@@ -301,15 +301,9 @@ F3DS_HD bool a_eval_R_step(const SweepView& s, const uint32_t* ownR, int w) {
 // Can any lower helper steal w at all, whatever the R of its leaves?  False means R(w) holds without looking at
 // any other voxel; the full sweeps settle most voxels this way and run the chain walker on the rest only.
 // (Same tests as a_eval_R_step with every neighbour's R taken as true; not for sweeps with ghost leaves.)
-F3DS_HD bool a_has_thief(const SweepView& s, int w) {
-    const uint32_t h = s.owner[w];
+// (decision part, shared with the LDS-tiled kernels: og[k] = owner of neighbour k when that is a lower label than h, else 0)
+F3DS_HD bool a_has_thief_og(const SweepView& s, int w, const uint32_t og[27]) {
     const float dw = s.dist[w];
-    int nu[27]; uint32_t og[27];
-    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
-    for (int k = 0; k < 27; ++k) {
-        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];
-        og[k] = (nu[k] >= 0 && g != 0u && g < h) ? g : 0u;
-    }
     float wrow[12];
     a_load_row(s.vf + (size_t)w * 12, wrow);
     uint32_t last = 0;
@@ -321,19 +315,23 @@ F3DS_HD bool a_has_thief(const SweepView& s, int w) {
         if (a_helper_dist_row(s, g, wrow) < dw) return true;
     }
 }
+F3DS_HD bool a_has_thief(const SweepView& s, int w) {
+    const uint32_t h = s.owner[w];
+    int nu[27]; uint32_t og[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
+    for (int k = 0; k < 27; ++k) {
+        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];
+        og[k] = (nu[k] >= 0 && g != 0u && g < h) ? g : 0u;
+    }
+    return a_has_thief_og(s, w, og);
+}
 // state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
 // (written by the R pass for every voxel), so a neighbour costs one gather.  ghost_done[g] is set
 // when helper g turns its ghost leaf on v into a real one (only the thread of v writes it).
-F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* owner_out, float* dist_out, unsigned char* ghost_done) {
-    const bool ghosts = *s.n_ghosts != 0u;
+// (decision part without ghost leaves, shared with the LDS-tiled kernels: cand[k] = helper that offers v through neighbour k, 0 = none)
+F3DS_HD void a_claim_cand(const SweepView& s, int v, const uint32_t cand[27], uint32_t* owner_out, float* dist_out) {
     uint32_t o = s.owner[v];
     float d = s.dist[v];
-    int nu[27]; uint32_t cand[27];
-    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, v, k);
-    for (int k = 0; k < 27; ++k) {
-        const uint32_t x = ownR[nu[k] >= 0 ? nu[k] : v];               // unconditional loads, see a_eval_R
-        cand[k] = (nu[k] >= 0 && (x & F3DS_OWNR_RTRUE)) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
-    }
     float vrow[12];
     a_load_row(s.vf + (size_t)v * 12, vrow);
     uint32_t last = 0;
@@ -343,22 +341,48 @@ F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* 
             const uint32_t gu = cand[k];
             if (gu > last && gu < g) g = gu;
         }
-        if (ghosts)
-            for (int k = 0; k < 27; ++k) {
-                const int u = a_nbr(s, v, k);
-                if (u < 0) continue;
-                for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
-                    if (gg > last && gg < g) g = gg;
-            }
+        if (g == 0xFFFFFFFFu) break;
+        last = g;
+        if (g == o) continue;          // neighbor_voxel.owner_ == this
+        float dg = a_helper_dist_row(s, g, vrow);
+        if (dg < d) { d = dg; o = g; }
+    }
+    *owner_out = o; *dist_out = d;
+}
+F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* owner_out, float* dist_out, unsigned char* ghost_done) {
+    const bool ghosts = *s.n_ghosts != 0u;
+    int nu[27]; uint32_t cand[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, v, k);
+    for (int k = 0; k < 27; ++k) {
+        const uint32_t x = ownR[nu[k] >= 0 ? nu[k] : v];               // unconditional loads, see a_eval_R
+        cand[k] = (nu[k] >= 0 && (x & F3DS_OWNR_RTRUE)) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
+    }
+    if (!ghosts) { a_claim_cand(s, v, cand, owner_out, dist_out); return; }
+    uint32_t o = s.owner[v];
+    float d = s.dist[v];
+    float vrow[12];
+    a_load_row(s.vf + (size_t)v * 12, vrow);
+    uint32_t last = 0;
+    for (;;) {
+        uint32_t g = 0xFFFFFFFFu;     // smallest candidate label above `last`
+        for (int k = 0; k < 27; ++k) {
+            const uint32_t gu = cand[k];
+            if (gu > last && gu < g) g = gu;
+        }
+        for (int k = 0; k < 27; ++k) {
+            const int u = a_nbr(s, v, k);
+            if (u < 0) continue;
+            for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
+                if (gg > last && gg < g) g = gg;
+        }
         if (g == 0xFFFFFFFFu) break;
         last = g;
         if (g == o) continue;          // neighbor_voxel.owner_ == this
         float dg = a_helper_dist_row(s, g, vrow);
         if (dg < d) {
             d = dg; o = g;
-            if (ghosts)
-                for (uint32_t gg = s.ghost_head[v]; gg != 0u; gg = s.ghost_next[gg])
-                    if (gg == g) ghost_done[g] = 1;
+            for (uint32_t gg = s.ghost_head[v]; gg != 0u; gg = s.ghost_next[gg])
+                if (gg == g) ghost_done[g] = 1;
         }
     }
     *owner_out = o; *dist_out = d;

@@ -146,7 +146,7 @@ struct f3ds_ctx {
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
     Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
-    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, rincl;
+    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
 
@@ -463,7 +463,11 @@ int seg_voxels(f3ds_ctx* c) {
 // stage 1b: voxel normals -- ONE launch per batch call, bracketed by its own pair of events (f3ds_result.ms_stage[7]: besides the merge
 // loop the only kernel of the path whose launch duration is measured live, bench.py's roofline picks the longer of the two)
 int seg_normals(f3ds_ctx* c) {
-    rec<d_normals>(c, (c->V + NT_TILE - 1) / NT_TILE, 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc);
+    const uint32_t nt = (c->V + NT_TILE - 1) / NT_TILE;
+    uint32_t *tn1, *tord, *tslots;      // the tiles' one-ring tables, built on the way for the sweeps (d_sweep_R_pre, d_sweep_claim)
+    ENSURE(c->tile_n1, uint32_t, nt, tn1); ENSURE(c->tile_ord, uint32_t, (size_t)nt * NT_RING1, tord); ENSURE(c->tile_slots, uint32_t, (size_t)nt * SW_SLOT_WORDS * NT_TILE, tslots);
+    rec<d_normals>(c, nt, 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots,
+                   (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0));
     return F3DS_OK;
 }
 // stage 2a: seed grid growth
@@ -556,6 +560,9 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
     a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.chg = chg; a.wl = wl; a.wl2 = wl2;
     a.thr = g_inc_shift >= 32 ? 0xFFFFFFFFu : (g_inc_shift < 0 ? 0u : V >> g_inc_shift);
+    if (getenv("F3DS_SWEEP_TILES") && !atoi(getenv("F3DS_SWEEP_TILES"))) a.tile_n1 = nullptr;      // development: F3DS_SWEEP_TILES=0 keeps the sweeps on their global-gather path (A/B, tests)
+    else a.tile_n1 = (const uint32_t*)c->tile_n1.p;
+    a.tile_ord = (const uint32_t*)c->tile_ord.p; a.tile_slots = (const uint32_t*)c->tile_slots.p;
     for (uint32_t t = 0; t < c->res.sweeps; ++t) {
         if (a_sweep_needs_clear(t)) rec_fill(c, R, 0u, V);
         rec<d_sweep_begin>(c, 1u, 0u, a, t);
@@ -715,6 +722,12 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
 }
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
+    if (const char* e = getenv("F3DS_FAKE_MERGE")) {      // experiment, timing only: see d_fake_merge
+        unsigned us = 30000, waves = 1; sscanf(e, "%u,%u", &us, &waves);
+        const char* l = getenv("F3DS_FAKE_MERGE_LDS");
+        rec<d_fake_merge>(c, 1u, l ? (uint32_t)atoi(l) * 1024u : c->mlds.lds_bytes, c->mdev, (uint32_t)us, (uint32_t)waves);
+        return F3DS_OK;
+    }
     switch (c->merge_kind) {
         case MK_CW + 0: rec<d_merge_cw_t<2, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         case MK_CW + 1: rec<d_merge_cw_t<2, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
