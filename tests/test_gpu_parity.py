@@ -888,3 +888,31 @@ def test_cli_gpus_unreadable_file_and_bench_flag(P, oracle, tmp_path):
     assert line["frames"] == 20 and line["gpus"] == 1 and line["mpoints_per_s"] > 0
     r = subprocess.run([exe, "--bench", "4"], capture_output=True, text=True, cwd=str(tmp_path))      # no -t
     assert r.returncode == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(F3DS_SWEEP_TILES="0"), dict(F3DS_SWEEP_TILE_HOLES="3"), dict(F3DS_SWEEP_TILE_HOLES="2", F3DS_INC_SHIFT="32")],
+                         ids=["global-gathers", "every-third-tile-global", "holes-and-always-incremental"])
+def test_lds_tiled_sweeps_equal_the_global_gather_sweeps(P, env):
+    """d_sweep_R_pre / d_sweep_claim read a voxel's 27 neighbours from an LDS copy of its 128-voxel tile's one-ring (tables written by
+    d_normals); tiles whose one-ring overflowed, and sweeps with ghost leaves, gather from global memory instead.  The default (all
+    tiles staged) is what every other test runs; here the global path alone, and a mix of both inside one launch (every n-th tile
+    declared overflowed), with full and with incremental sweeps, against the golden hashes.  The switches are read per call except
+    F3DS_INC_SHIFT (library load), hence the child process."""
+    import subprocess, sys
+    names = ["rgbd_320x240_ghosts", "rgbd_320x240_large_supervoxels", "fixture_launch_flags", "fused_200k_nan_lambda"]
+    code = (
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import conftest; from golden_cases import case_points, case_params\n"
+        "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
+        "for n in %r:\n"
+        "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
+        "    out[n] = dict(labels=conftest.sha_of(lab), **{w: conftest.sha_of(ctx.debug(w)) for w in ('VOXEL_SVLABEL', 'VOXEL_DIST', 'SV_CENTROID', 'MERGES')})\n"
+        "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    for n in names:
+        assert got[n]["labels"] == GOLD[n]["labels_sha256"], (n, env)
+        for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
+            assert got[n][w] == GOLD[n]["sha256"][w], (n, w, env)
