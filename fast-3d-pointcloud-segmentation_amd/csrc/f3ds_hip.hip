@@ -369,13 +369,14 @@ int flush_sync(Batch& b) {
     return F3DS_OK;
 }
 
-// inclusive scan of n uint32 values (in -> out): always the same two calls so that frames of
+// inclusive scan of n uint32 values (in -> out): always the same three calls so that frames of
 // different sizes record identical sequences
 int scan_u32(f3ds_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
     const uint32_t nt = n ? (n + SCAN_TILE - 1) / SCAN_TILE : 1u;
     uint32_t* tiles;
     ENSURE(c->tiles, uint32_t, nt, tiles);
-    rec<d_scan_tiles>(c, nt, 0u, in, out, tiles, n, &c->d_dc->scan_ticket);      // (its last workgroup turns the tile sums into offsets)
+    rec<d_scan_tiles>(c, nt, 0u, in, out, tiles, n);
+    rec<d_scan_single>(c, 1u, 0u, tiles, nt);
     rec<d_scan_add>(c, nt, 0u, out, (const uint32_t*)tiles, n);
     return F3DS_OK;
 }
@@ -391,7 +392,8 @@ int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* 
     int shift = 0;
     for (int p = 0; p < passes; ++p) {
         const int bits = (total_bits - shift) < per ? (total_bits - shift) : per;
-        rec<d_radix_hist>(c, nb, 0u, (const uint64_t*)k0, n, base_shift + shift, bits, hist, nb, &c->d_dc->scan_ticket);      // counts, and their scan by the last workgroup
+        rec<d_radix_hist>(c, nb, 0u, (const uint64_t*)k0, n, base_shift + shift, bits, hist, nb);
+        rec<d_scan_single>(c, 1u, 0u, hist, (uint32_t)((1u << bits) * nb));
         if (v0) rec<d_radix_scatter>(c, nb, 0u, (const uint64_t*)k0, (const uint32_t*)v0, k1, v1, n, base_shift + shift, bits, (const uint32_t*)hist, nb);
         else rec<d_radix_scatter_k>(c, nb, 0u, (const uint64_t*)k0, k1, n, base_shift + shift, bits, (const uint32_t*)hist, nb);      // payload in the key's low bits
         std::swap(k0, k1); std::swap(v0, v1);
@@ -432,7 +434,8 @@ int seg_sort(f3ds_ctx* c, int sort_bits, int idxbits) {      // idxbits >= 0: (c
     }
     const uint32_t nt = n ? (n + SCAN_TILE - 1) / SCAN_TILE : 1u;
     uint32_t* tiles; ENSURE(c->tiles, uint32_t, nt, tiles);
-    rec<d_seg_count>(c, nt, 0u, (const uint64_t*)c->ks, n, invalid, ks, tiles, &c->d_dc->scan_ticket);
+    rec<d_seg_count>(c, nt, 0u, (const uint64_t*)c->ks, n, invalid, ks, tiles);
+    rec<d_scan_single>(c, 1u, 0u, tiles, nt);
     rec<d_seg_write>(c, nt, 0u, (const uint64_t*)c->ks, n, invalid, ks, (const uint32_t*)tiles, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid);
     return F3DS_OK;
 }
