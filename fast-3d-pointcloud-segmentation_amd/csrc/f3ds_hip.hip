@@ -235,6 +235,7 @@ int pregrow_scratch(f3ds_ctx* c) {
 // 300 thin ones (per-workgroup prologue: argument pack, counters, stamps), see DESIGN.md 4b.  The hash-probing /
 // gathering kernels want every wave they can get and keep the old cap (grid_wide).  Set per batch call (one host thread).
 thread_local size_t g_grid_cap = 2048;
+thread_local int g_batch_frames = 1;      // frames of the batch call this thread is running
 size_t grid_cap_for_batch(int frames) {
     static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
     if (!target) return 2048;
@@ -466,7 +467,10 @@ int seg_normals(f3ds_ctx* c) {
     const uint32_t nt = (c->V + NT_TILE - 1) / NT_TILE;
     uint32_t *tn1, *tord, *tslots;      // the tiles' one-ring tables, built on the way for the sweeps (d_sweep_R_pre, d_sweep_claim)
     ENSURE(c->tile_n1, uint32_t, nt, tn1); ENSURE(c->tile_ord, uint32_t, (size_t)nt * NT_RING1, tord); ENSURE(c->tile_slots, uint32_t, (size_t)nt * SW_SLOT_WORDS * NT_TILE, tslots);
-    rec<d_normals>(c, nt, 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots,
+    // workgroups per frame: its share of a launch-wide budget (two per compute unit fit), every workgroup then walks a run of tiles
+    static const uint32_t budget = getenv("F3DS_NORMALS_WGS") ? (uint32_t)atoi(getenv("F3DS_NORMALS_WGS")) : 1024u;
+    const uint32_t share = budget ? std::max(2u, budget / (uint32_t)g_batch_frames) : nt;
+    rec<d_normals>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots,
                    (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0));
     return F3DS_OK;
 }
@@ -952,7 +956,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     b.owner = ctxs[0]; b.st = ctxs[0]->stream;
     BatchStreamLease lease;
     if (nctx > 1 && ctxs[0]->stream == ctxs[0]->own_stream && !getenv("F3DS_NO_STREAM_POOL")) { hipStream_t ps = lease.acquire(ctxs[0]->device); if (ps) b.st = ps; }
-    g_grid_cap = grid_cap_for_batch(nctx);
+    g_grid_cap = grid_cap_for_batch(nctx); g_batch_frames = nctx;
     std::vector<int> index_of;
     const int max_depth = (int)(1.8f * prm->seed_res / prm->voxel_res);      // [PCL-recall] SupervoxelClustering::extract
     const uint32_t sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0u;
@@ -1069,7 +1073,7 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHECK(hipSetDevice(c->device));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
     c->cmds.clear(); c->blob.clear(); c->pend.clear();
     c->h_dc->error = 0;
     HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), c->stream));
@@ -1163,7 +1167,7 @@ extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
     if (!c || num_itr < 0) return F3DS_ERR_ARG;
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     HIPCHECK(hipSetDevice(c->device));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
     c->cmds.clear(); c->blob.clear(); c->pend.clear();
     c->refined_itr = -1;
     const uint32_t V = c->V, S0 = c->S0;
@@ -1375,7 +1379,7 @@ int eval_truth(f3ds_ctx* c, const uint32_t* truth_point_labels) {
     HIPCHECK(hipMemcpyAsync(lut, f3ds_glasbey_256, 1024, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemcpyAsync(tp, truth_point_labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemsetAsync(tsum, 0, (size_t)V * 12, c->stream));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
     c->cmds.clear(); c->blob.clear(); c->pend.clear();
     rec<d_truth_accum>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)tp, (const uint32_t*)lut, tsum);
     rec<d_truth_color>(c, grid_for(V, 256), 0u, V, (const uint32_t*)tsum, (const uint32_t*)c->vcount.p, tcol);
@@ -1403,7 +1407,7 @@ int eval_scores(f3ds_ctx* c, const uint32_t* d_root, const uint32_t* d_incl, uin
     ENSURE(c->ctab, uint32_t, (size_t)K * M, tab); ENSURE(c->csize, uint32_t, K, ssz);
     HIPCHECK(hipMemsetAsync(tab, 0, (size_t)K * M * 4, c->stream));
     HIPCHECK(hipMemsetAsync(ssz, 0, (size_t)K * 4, c->stream));
-    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1);
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
     c->cmds.clear(); c->blob.clear(); c->pend.clear();
     rec<d_contingency>(c, grid_for(V, 256), 0u, V, M, (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
     rec<d_contingency_ghost>(c, grid_for(c->S0, 256), 0u, c->S0, M, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p,
