@@ -467,8 +467,11 @@ int seg_normals(f3ds_ctx* c) {
     const uint32_t nt = (c->V + NT_TILE - 1) / NT_TILE;
     uint32_t *tn1, *tord, *tslots;      // the tiles' one-ring tables, built on the way for the sweeps (d_sweep_R_pre, d_sweep_claim)
     ENSURE(c->tile_n1, uint32_t, nt, tn1); ENSURE(c->tile_ord, uint32_t, (size_t)nt * NT_RING1, tord); ENSURE(c->tile_slots, uint32_t, (size_t)nt * SW_SLOT_WORDS * NT_TILE, tslots);
-    // workgroups per frame: its share of a launch-wide budget (two per compute unit fit), every workgroup then walks a run of tiles
-    static const uint32_t budget = getenv("F3DS_NORMALS_WGS") ? (uint32_t)atoi(getenv("F3DS_NORMALS_WGS")) : 1024u;
+    // One workgroup per tile by default.  F3DS_NORMALS_WGS=<n> (experiment): a launch-wide budget of n workgroups, each walking a run of
+    // tiles -- placed once, a 72 KB six-wave workgroup then keeps its compute unit instead of competing for one per tile.  With six calls in flight the
+    // launch drops from 50-100 ms to 30 ms and the sweeps of the other calls grow by as much (2 140-2 155 vs 2 170 Mpoints/s on one box); alone it is
+    // twice as slow (83 vs 43 us per frame: two rounds of long-lived workgroups).  The chip's compute-unit time is conserved; only work removed counts.
+    static const uint32_t budget = getenv("F3DS_NORMALS_WGS") ? (uint32_t)atoi(getenv("F3DS_NORMALS_WGS")) : 0u;
     const uint32_t share = budget ? std::max(2u, budget / (uint32_t)g_batch_frames) : nt;
     rec<d_normals>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots,
                    (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0));
