@@ -1,21 +1,22 @@
 #!/bin/bash
-# On the GPU box (through gpurun): everything profiles/r2_* is built from, into gpurun_out/<tag>_*.
+# On the GPU box (through gpurun): everything profiles/<tag>_* is built from, into gpurun_out/<tag>_*.
 #   tools/refresh_profiles.sh <tag>
 # Then here: cp the summaries named at the end of this script into profiles/.
-tag=${1:-r2}
+tag=${1:-r3}
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 # 1. the bench line as the driver runs it, and with the default flags
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_driver_flags.json 2> gpurun_out/${tag}_bench.err
 timeout 600 python3 bench.py > gpurun_out/${tag}_bench.json 2>> gpurun_out/${tag}_bench.err
-# 2. per-kernel times of the same command (four calls in flight: durations include sharing the chip) + what the GPU does over time
+# 2. per-kernel times of the same command (six calls in flight: durations include sharing the chip) + what the GPU does over time
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_stats -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --host-io-steps 0 --no-cpu-baseline > $R/gpurun_out/${tag}_stats.log 2>&1
 cd $R; cp $(find /tmp/${tag}_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
 python3 tools/timeline.py /tmp/${tag}_stats 0.45 > gpurun_out/${tag}_timeline.txt 2>&1
-# 3. one call of 192 frames at a time: per-kernel cost without contention
+# 3. one call of 192 frames at a time: per-kernel cost without contention, and the sweep kernels launch by launch
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_iso -- python3 $R/bench.py --groups 1 --batch 192 --steps 9 --warmup 3 --host-io-steps 0 --no-cpu-baseline > $R/gpurun_out/${tag}_iso.log 2>&1
 cd $R; cp $(find /tmp/${tag}_iso -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats_isolated.csv
+python3 tools/sweep_trace.py /tmp/${tag}_iso 192 > gpurun_out/${tag}_sweep_trace.txt 2>&1
 # 4. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (one call of 96 frames at a time, equal calls)
 for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && F3DS_BENCH_RAMP=0 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${tag}_pmc_$c -- python3 $R/bench.py --groups 1 --batch 96 --steps 3 --warmup 0 --host-io-steps 0 --no-cpu-baseline > $R/gpurun_out/${tag}_pmc_$c.log 2>&1
@@ -24,4 +25,18 @@ cd $R
 # the profiled run processes: 2 set-up passes of 96 + 3 steps of 64 + 3 latency frames
 python3 tools/pmc_summary.py /tmp/${tag}_pmc_FETCH_SIZE /tmp/${tag}_pmc_WRITE_SIZE 96 gpurun_out/${tag}_pmc_hbm_traffic.json 387 > gpurun_out/${tag}_pmc_summary.txt 2>&1
 tail -20 gpurun_out/${tag}_pmc_summary.txt
-echo "copy to profiles/: ${tag}_bench.json ${tag}_bench_driver_flags.json ${tag}_kernel_stats.csv ${tag}_kernel_stats_isolated.csv ${tag}_timeline.txt ${tag}_pmc_hbm_traffic.json"
+# 5. BASELINE config 4 (the 20M-point scene): stage times, per-kernel stats, merge-loop phase probes (PROF build), HBM traffic
+python3 tools/config4_frame.py 4 > gpurun_out/${tag}_config4_stages.txt 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_c4 -- python3 $R/tools/config4_frame.py 4 > $R/gpurun_out/${tag}_config4.log 2>&1
+cd $R; cp $(find /tmp/${tag}_c4 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_config4_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${tag}_c4pmc_$c -- python3 $R/tools/config4_frame.py 2 > $R/gpurun_out/${tag}_c4pmc_$c.log 2>&1
+done
+cd $R
+python3 tools/pmc_summary.py /tmp/${tag}_c4pmc_FETCH_SIZE /tmp/${tag}_c4pmc_WRITE_SIZE 1 gpurun_out/${tag}_config4_pmc_hbm_traffic.json 2 > gpurun_out/${tag}_config4_pmc_summary.txt 2>&1
+tail -12 gpurun_out/${tag}_config4_pmc_summary.txt
+if [ -f fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so ]; then
+  F3DS_LIB=$R/fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so python3 tools/lone_frame.py 3 > gpurun_out/${tag}_merge_prof_raw.txt 2>&1
+  F3DS_LIB=$R/fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so python3 tools/config4_frame.py 2 > gpurun_out/${tag}_config4_merge_prof_raw.txt 2>&1
+fi
+echo "copy to profiles/: ${tag}_bench.json ${tag}_bench_driver_flags.json ${tag}_kernel_stats.csv ${tag}_kernel_stats_isolated.csv ${tag}_timeline.txt ${tag}_sweep_trace.txt ${tag}_pmc_hbm_traffic.json ${tag}_config4_*"
