@@ -634,7 +634,12 @@ bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {  
     xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
     const uint64_t fixed = (uint64_t)xl->Ecap * 4u * (uint32_t)res + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
     const uint64_t stage_off = (fixed + 15u) & ~(uint64_t)15u;
-    const uint64_t total = stage_off + 2u * CH * 52u + 64u;      // (+ 64: the fold loops read up to 16 rows ahead)
+    uint64_t total = stage_off + 2u * CH * 52u + 64u;      // (+ 64: the fold loops read up to 16 rows ahead)
+    xl->stage2_off = 0u; xl->spec = 0;
+    if (nw == 8) {      // staging area of an epoch's speculative second merge, switched off by F3DS_MERGE_SPEC=0
+        xl->stage2_off = (uint32_t)total; total += (uint64_t)MC_SP_ROWS * 52u + (uint64_t)MC_SP_TL * 8u + 64u;
+        xl->spec = (getenv("F3DS_MERGE_SPEC") && !atoi(getenv("F3DS_MERGE_SPEC"))) ? 0 : 1;
+    }
     xl->stage_off = (uint32_t)stage_off; xl->lds_bytes = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
     xl->keys_in_lds = res;
     return total <= 160u * 1024u - 2048u && S0 <= 65534u;      // (2 KB: the kernel's static LDS)
