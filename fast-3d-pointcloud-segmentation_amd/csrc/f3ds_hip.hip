@@ -471,7 +471,11 @@ int seg_normals(f3ds_ctx* c) {
     // tiles -- placed once, a 72 KB six-wave workgroup then keeps its compute unit instead of competing for one per tile.  With six calls in flight the
     // launch drops from 50-100 ms to 30 ms and the sweeps of the other calls grow by as much (2 140-2 155 vs 2 170 Mpoints/s on one box); alone it is
     // twice as slow (83 vs 43 us per frame: two rounds of long-lived workgroups).  The chip's compute-unit time is conserved; only work removed counts.
+#ifdef F3DS_NORMALS_LOOP
     static const uint32_t budget = getenv("F3DS_NORMALS_WGS") ? (uint32_t)atoi(getenv("F3DS_NORMALS_WGS")) : 0u;
+#else
+    static const uint32_t budget = 0u;      // (the tile loop is compiled in with make EXTRA=-DF3DS_NORMALS_LOOP only)
+#endif
     const uint32_t share = budget ? std::max(2u, budget / (uint32_t)g_batch_frames) : nt;
     rec<d_normals>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots,
                    (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0));
