@@ -295,7 +295,7 @@ static int trace_err(int code, const char* where, const f3ds_ctx* c) {
 }
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // zip the recorded calls of all live frames into batched dispatches
-int flush(Batch& b) {
+int flush(Batch& b, hipEvent_t before_launch = nullptr) {      // before_launch: recorded after the argument upload, right before the first dispatch
     if (b.fr.empty()) return F3DS_OK;
     const size_t ncmd = b.fr[0]->cmds.size();
     for (f3ds_ctx* c : b.fr) if (c->cmds.size() != ncmd) return F3DS_ERR_UNSUPPORTED;   // frames must take the same path
@@ -333,6 +333,7 @@ int flush(Batch& b) {
             memcpy(h_args + off[j] + (size_t)i * cm.bytes, b.fr[i]->blob.data() + cm.off, cm.bytes);
         }
     HIPCHECK(hipMemcpyAsync(d_args, h_args, total, hipMemcpyHostToDevice, b.st));
+    if (before_launch) HIPCHECK(hipEventRecord(before_launch, b.st));
     for (size_t j = 0; j < ncmd; ++j) {
         uint32_t gx = 1, lds = 0;
         for (uint32_t i = 0; i < nf; ++i) { const Cmd& cm = b.fr[i]->cmds[j]; if (cm.gx > gx) gx = cm.gx; if (cm.lds > lds) lds = cm.lds; }
@@ -1022,8 +1023,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     stage_mark(b, 1);
     // ---- stage 1 + 2: neighbours, normals, seeds
     if ((rc = for_frames(b, seg_voxels)) || (rc = flush(b))) return rc;
-    stage_mark(b, 9);
-    if ((rc = for_frames(b, seg_normals)) || (rc = flush(b))) return rc;
+    if ((rc = for_frames(b, seg_normals)) || (rc = flush(b, b.owner->ev[9]))) return rc;      // (the event pair brackets the dispatch alone, not its argument upload)
     stage_mark(b, 10);
     if ((rc = for_frames(b, seg_seed_grid)) || (rc = flush(b))) return rc;
     stage_mark(b, 2);
