@@ -267,8 +267,10 @@ def main():
         value = world * total_frames * npts / elapsed / 1e6
         mean_stage = [m / max(1, calls_done[0]) for m in stage_ms]       # per batched launch sequence
         frames_per_launch = frames_done[0] / max(1, calls_done[0])
-        # The dominant KERNEL, from what this run measured: the merge loop and the voxel normals are each ONE launch per call with their own
-        # pair of HIP events on the call's stream (f3ds_result.ms_stage[5] / [7]); the other stages are sequences of many launches of several
+        # The dominant KERNEL, from what this run measured: the merge loop and the voxel normals are each ONE launch per call and timed on their own
+        # (f3ds_result.ms_stage[5]: HIP events on the call's stream around the merge dispatch; ms_stage[7]: the normals launch's execution window on the
+        # device clock, first workgroup started .. last one ended -- an event pair around that dispatch also counts the 10-15 ms it waits at the head of its
+        # queue for a compute unit with 72 KB of LDS free, which a kernel trace does not); the other stages are sequences of many launches of several
         # kernels (their per-kernel split is in profiles/r3_kernel_stats*.csv) and are reported as stages below.
         KERNELS = {5: ("k_batched<d_merge_cw_t<8,2>>", "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals>", "neighbours+normals", "d_normals")}
         dom = max(KERNELS, key=lambda j: stage_ms[j])

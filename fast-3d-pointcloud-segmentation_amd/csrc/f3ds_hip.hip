@@ -236,6 +236,7 @@ int pregrow_scratch(f3ds_ctx* c) {
 // gathering kernels want every wave they can get and keep the old cap (grid_wide).  Set per batch call (one host thread).
 thread_local size_t g_grid_cap = 2048;
 thread_local int g_batch_frames = 1;      // frames of the batch call this thread is running
+thread_local unsigned long long g_norm_t0 = ~0ull, g_norm_t1 = 0ull;      // device-clock window of the call's d_normals launch
 size_t grid_cap_for_batch(int frames) {
     static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
     if (!target) return 2048;
@@ -1028,6 +1029,8 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = for_frames(b, seg_seed_grid)) || (rc = flush(b))) return rc;
     stage_mark(b, 2);
     if ((rc = flush_sync(b))) return rc;
+    g_norm_t0 = ~0ull; g_norm_t1 = 0ull;
+    for (f3ds_ctx* c : b.fr) { if (c->h_dc->t_norm0 < g_norm_t0) g_norm_t0 = c->h_dc->t_norm0; if (c->h_dc->t_norm1 > g_norm_t1) g_norm_t1 = c->h_dc->t_norm1; }
     int maxsd = 0;
     for (f3ds_ctx* c : b.fr) { if (c->h_dc->error) return c->h_dc->error; if (c->h_dc->sdepth > maxsd) maxsd = c->h_dc->sdepth; }
     if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_seed_cells(c, 3 * maxsd, maxsd); })) || (rc = flush_sync(b))) return rc;
@@ -1068,7 +1071,11 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     float stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // device time of each stage of the whole batch (HIP events on the batch's stream)
     for (int k = 0; k < 7; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[k], b.owner->ev[k + 1]) == hipSuccess) stage[k] = ms; }
-    if (!b.fr.empty()) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[9], b.owner->ev[10]) == hipSuccess) stage[7] = ms; }      // the d_normals launch (inside stage 1)
+    // the d_normals launch (inside stage 1): its execution window on the device clock -- first workgroup started to last workgroup ended, over the frames of the
+    // call: what a kernel trace calls its duration.  (The HIP-event pair around the dispatch reads 10-15 ms more with six calls in flight: the time the dispatch
+    // sits at the head of its queue before a compute unit has 72 KB of LDS and six wave slots free for its first workgroup.)
+    if (g_norm_t1 > g_norm_t0) stage[7] = (float)((double)(g_norm_t1 - g_norm_t0) * 1e-5);
+    else if (!b.fr.empty()) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[9], b.owner->ev[10]) == hipSuccess) stage[7] = ms; }
     const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (getenv("F3DS_HOST_PROF")) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic; stages %.0f %.0f %.0f %.0f %.0f %.0f %.0f ms; %llu scratch allocations so far\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch, stage[0], stage[1], stage[2], stage[3], stage[4], stage[5], stage[6], g_scratch_allocs.load());
     for (int i = 0; i < nctx; ++i) {

@@ -91,7 +91,8 @@ typedef struct f3ds_result {
     float ms_stage[8];            /* device time per stage (HIP events): 0 voxelise,
                                      1 neighbours+normals, 2 seeds, 3 sweeps, 4 supervoxel
                                      summaries+edges, 5 merge, 6 labels; 7 = the voxel-normal
-                                     kernel's launch alone (part of stage 1)             */
+                                     kernel's launch alone (part of stage 1): first workgroup
+                                     started .. last one ended, on the device's clock   */
 } f3ds_result;
 
 typedef struct f3ds_ctx f3ds_ctx;
