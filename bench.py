@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1000)
     ap.add_argument("--height", type=int, default=1000)
     ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the pinned-host-in / host-out pass (default min(steps, 12); 0 = skip)")
+    ap.add_argument("--host-io-groups", type=int, default=0, help="batch calls in flight in the host-in / host-out pass (0 = as --groups): a call is longer there by its PCIe copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -128,9 +129,10 @@ def main():
         frames_host = list(ex.map(lambda s: P.synth_frame(0, s, args.width, args.height, 30), seeds))
     frames_dev = [torch.from_numpy(f).to(dev) for f in frames_host]
     nbatch, ngroups = max(1, args.batch), max(1, args.groups)
-    ctxs = [[P.Context(local_rank) for _ in range(nbatch)] for _ in range(ngroups)]
+    hgroups = args.host_io_groups if args.host_io_groups > 0 else ngroups
+    ctxs = [[P.Context(local_rank) for _ in range(nbatch)] for _ in range(max(ngroups, hgroups))]
     # label output: a ring of per-step blocks [64, npts]; a step's block is ONE RCCL gather (64 x 4 MB per rank)
-    n_blocks = -(-(nbatch * ngroups) // FPS) + 2
+    n_blocks = -(-(nbatch * max(ngroups, hgroups)) // FPS) + 2
     label_blocks = [torch.empty((FPS, npts), dtype=torch.int32, device=dev) for _ in range(n_blocks)]
     gather_list = [torch.empty((FPS, npts), dtype=torch.int32, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None
     gather_stream = torch.cuda.Stream(device=dev) if dist_on else None
@@ -177,7 +179,7 @@ def main():
     # set-up, not warm-up: every context grows its device scratch on first use (hipMalloc), so each is used once before
     # the W warm-up steps, however small W is; the timed region never allocates
     def use_every_context():
-        ts = [threading.Thread(target=run_batch, args=(g, g * nbatch, (g + 1) * nbatch)) for g in range(ngroups)]
+        ts = [threading.Thread(target=run_batch, args=(g, g * nbatch, (g + 1) * nbatch)) for g in range(len(ctxs))]
         for t in ts:
             t.start()
         for t in ts:
@@ -209,7 +211,7 @@ def main():
         host_frames.extend(torch.from_numpy(f).pin_memory() for f in frames_host)
         host_labels.extend(torch.empty((FPS, npts), dtype=torch.int32).pin_memory() for _ in range(n_blocks))
         mode["host"] = True
-        hpipe = B.StepPipeline(FPS, nbatch, ngroups, n_blocks, run_batch, None, ramp=ramp)
+        hpipe = B.StepPipeline(FPS, nbatch, hgroups, n_blocks, run_batch, None, ramp=ramp)
         use_every_context()                                 # contexts allocate their upload buffers once
         barrier()
         th = time.perf_counter()
@@ -221,6 +223,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_h = float(t.item())
         host_io = {"value": round(world * hio_steps * FPS * npts / el_h / 1e6, 3), "unit": "Mpoints/s", "steps": hio_steps,
+                   "concurrent_calls": hgroups,
                    "what": "same loop, frames in pinned host memory, labels delivered to pinned host memory (no RCCL gather in this pass)"}
         mode["host"] = False
 
