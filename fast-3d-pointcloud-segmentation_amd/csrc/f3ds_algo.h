@@ -332,6 +332,9 @@ F3DS_HD bool a_has_thief(const SweepView& s, int w) {
 F3DS_HD void a_claim_cand(const SweepView& s, int v, const uint32_t cand[27], uint32_t* owner_out, float* dist_out) {
     uint32_t o = s.owner[v];
     float d = s.dist[v];
+#if defined(F3DS_EXP_CLAIM_NOSEL)      // timing experiment: no candidate search at all (wrong results)
+    { uint32_t x = 0; for (int k = 0; k < 27; ++k) x |= cand[k]; *owner_out = x == 0xFFFFFFFFu ? 1u : o; *dist_out = d; return; }
+#endif
     float vrow[12];
     a_load_row(s.vf + (size_t)v * 12, vrow);
     uint32_t last = 0;
@@ -344,7 +347,11 @@ F3DS_HD void a_claim_cand(const SweepView& s, int v, const uint32_t cand[27], ui
         if (g == 0xFFFFFFFFu) break;
         last = g;
         if (g == o) continue;          // neighbor_voxel.owner_ == this
+#if defined(F3DS_EXP_CLAIM_NODIST)     // timing experiment: candidates searched, no distance evaluated (wrong results)
+        float dg = (float)g + vrow[0];
+#else
         float dg = a_helper_dist_row(s, g, vrow);
+#endif
         if (dg < d) { d = dg; o = g; }
     }
     *owner_out = o; *dist_out = d;

@@ -579,14 +579,17 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     for (uint32_t t = 0; t < c->res.sweeps; ++t) {
         if (a_sweep_needs_clear(t)) rec_fill(c, R, 0u, V);
         rec<d_sweep_begin>(c, 1u, 0u, a, t);
-        if (g_inc_shift >= 0) for (uint32_t r = 0; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
+        // (sweeps 0 and 1 are full by construction -- d_sweep_begin: marking starts after a sweep t >= 1 at the earliest, and a sweep skips tiles only if the one
+        // before it was marking --, so their incremental launches would be no-ops on every frame: not recorded)
+        const bool can_skip = t >= 2u;
+        if (g_inc_shift >= 0 && can_skip) for (uint32_t r = 0; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
         rec<d_sweep_R_pre>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t);
         for (uint32_t pass = 0; pass < F3DS_R_PASSES; ++pass) rec<d_sweep_R>(c, pass == 0 ? grid_for(V, 256) : 64u, 0u, a, a_sweep_tag(t), t, pass);
         rec<d_sweep_R_tail>(c, 1u, 0u, a, a_sweep_tag(t), t);
         rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
-        if (g_inc_shift >= 0) rec<d_claim_mark>(c, grid_for(V, 256), 0u, a, t);
+        if (g_inc_shift >= 0 && t >= 1u) rec<d_claim_mark>(c, grid_for(V, 256), 0u, a, t);      // (sweep 0 never marks)
         rec<d_centroid>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
-        if (g_inc_shift >= 0) rec<d_centroid_mark>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
+        if (g_inc_shift >= 0 && t >= 1u) rec<d_centroid_mark>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
     }
     return F3DS_OK;
 }
