@@ -272,6 +272,34 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
     memo[w] = (unsigned char)(T | (stolen ? F3DS_R_FALSE : F3DS_R_TRUE));
     return !stolen;
 }
+// Smallest of 27 label words that lies above `last`, as (label - last - 1); a result >= F3DS_NO_NEXT = none.  The subtraction does the filtering: a word
+// at or below `last` -- including 0 = "no neighbour / no owner" -- wraps to a huge value and loses every minimum, so a candidate costs one subtract and
+// half a three-input minimum instead of two compares, an and and a select (the sweeps' stencil kernels are bound by the VALU instructions they issue: one
+// per four cycles per SIMD; the 27-wide search ran once per distinct candidate and was 3/4 of d_sweep_claim: DESIGN.md 4c).  `bias` = last + 1 for plain
+// labels; for ownR words (label | R bit in bit 31) bias = 0x80000000 + last + 1: a word with its R bit set gives label - last - 1 as before, one without
+// lands at or above 0x80000000 - last - 1.  Labels are below 2^30 (f3ds_segment refuses more seeds), so every rejected word reads >= 2^30 = F3DS_NO_NEXT.
+#define F3DS_NO_NEXT 0x40000000u
+F3DS_HD uint32_t a_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+F3DS_HD uint32_t a_next_label(const uint32_t x[27], uint32_t bias) {
+    uint32_t m[9];
+    for (int k = 0; k < 9; ++k) m[k] = a_umin(a_umin(x[3 * k] - bias, x[3 * k + 1] - bias), x[3 * k + 2] - bias);
+    return a_umin(a_umin(a_umin(m[0], m[1]), m[2]), a_umin(a_umin(a_umin(m[3], m[4]), m[5]), a_umin(a_umin(m[6], m[7]), m[8])));
+}
+// (decision part, shared with the LDS-tiled kernels: x[k] = sweep-start owner of neighbour k, 0 for an absent one; h = w's own owner.  Labels are visited
+// in ascending order and only those below h count: the search stops at the first one that is not)
+F3DS_HD bool a_has_thief_words(const SweepView& s, int w, uint32_t h, const uint32_t x[27]) {
+    const float dw = s.dist[w];
+    float wrow[12];
+    a_load_row(s.vf + (size_t)w * 12, wrow);
+    uint32_t last = 0;
+    for (;;) {
+        const uint32_t y = a_next_label(x, last + 1u);
+        const uint32_t g = y + last + 1u;
+        if (y >= F3DS_NO_NEXT || g >= h) return false;
+        last = g;
+        if (a_helper_dist_row(s, g, wrow) < dw) return true;
+    }
+}
 // One application of the defining equation of R to voxel w, reading the neighbours' R from bit 31 of
 // ownR instead of deriving it: the incremental sweeps (f3ds_kernels.inc, "dirty tiles") iterate this
 // to the fixed point, which is unique because R(w) only depends on R of voxels with a lower owner.
@@ -279,72 +307,46 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
 F3DS_HD bool a_eval_R_step(const SweepView& s, const uint32_t* ownR, int w) {
     const uint32_t h = s.owner[w];
     if (h == 0u) return false;
-    const float dw = s.dist[w];
-    int nu[27]; uint32_t og[27];
+    int nu[27]; uint32_t x[27];
     for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
     for (int k = 0; k < 27; ++k) {
         const int u = nu[k] >= 0 ? nu[k] : w;        // unconditional loads, see a_eval_R
-        const uint32_t g = s.owner[u], x = ownR[u];
-        og[k] = (nu[k] >= 0 && g != 0u && g < h && (x & F3DS_OWNR_RTRUE)) ? g : 0u;       // lower helper that still holds u at its turn (as far as ownR knows)
+        const uint32_t g = s.owner[u], r = ownR[u];
+        x[k] = (nu[k] >= 0 && (r & F3DS_OWNR_RTRUE)) ? g : 0u;       // helper that still holds u at its turn (as far as ownR knows)
     }
-    float wrow[12];
-    a_load_row(s.vf + (size_t)w * 12, wrow);
-    uint32_t last = 0;
-    for (;;) {
-        uint32_t g = 0xFFFFFFFFu;
-        for (int k = 0; k < 27; ++k) if (og[k] > last && og[k] < g) g = og[k];
-        if (g == 0xFFFFFFFFu) return true;
-        last = g;
-        if (a_helper_dist_row(s, g, wrow) < dw) return false;
-    }
+    return !a_has_thief_words(s, w, h, x);
 }
 // Can any lower helper steal w at all, whatever the R of its leaves?  False means R(w) holds without looking at
 // any other voxel; the full sweeps settle most voxels this way and run the chain walker on the rest only.
 // (Same tests as a_eval_R_step with every neighbour's R taken as true; not for sweeps with ghost leaves.)
-// (decision part, shared with the LDS-tiled kernels: og[k] = owner of neighbour k when that is a lower label than h, else 0)
-F3DS_HD bool a_has_thief_og(const SweepView& s, int w, const uint32_t og[27]) {
-    const float dw = s.dist[w];
-    float wrow[12];
-    a_load_row(s.vf + (size_t)w * 12, wrow);
-    uint32_t last = 0;
-    for (;;) {
-        uint32_t g = 0xFFFFFFFFu;
-        for (int k = 0; k < 27; ++k) if (og[k] > last && og[k] < g) g = og[k];
-        if (g == 0xFFFFFFFFu) return false;
-        last = g;
-        if (a_helper_dist_row(s, g, wrow) < dw) return true;
-    }
-}
 F3DS_HD bool a_has_thief(const SweepView& s, int w) {
     const uint32_t h = s.owner[w];
-    int nu[27]; uint32_t og[27];
+    int nu[27]; uint32_t x[27];
     for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
     for (int k = 0; k < 27; ++k) {
-        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];
-        og[k] = (nu[k] >= 0 && g != 0u && g < h) ? g : 0u;
+        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];           // unconditional loads, see a_eval_R
+        x[k] = nu[k] >= 0 ? g : 0u;
     }
-    return a_has_thief_og(s, w, og);
+    return a_has_thief_words(s, w, h, x);
 }
 // state of voxel v after the sweep.  ownR[u] = sweep-start owner of u with bit 31 set when R(u) holds
 // (written by the R pass for every voxel), so a neighbour costs one gather.  ghost_done[g] is set
 // when helper g turns its ghost leaf on v into a real one (only the thread of v writes it).
-// (decision part without ghost leaves, shared with the LDS-tiled kernels: cand[k] = helper that offers v through neighbour k, 0 = none)
-F3DS_HD void a_claim_cand(const SweepView& s, int v, const uint32_t cand[27], uint32_t* owner_out, float* dist_out) {
+// (decision part without ghost leaves, shared with the LDS-tiled kernels: x[k] = the ownR word of neighbour k -- its sweep-start owner, bit 31 set when
+// that owner still holds it at its turn --, 0 for an absent neighbour: the helpers that offer v are the labels of the words with bit 31 set)
+F3DS_HD void a_claim_words(const SweepView& s, int v, const uint32_t x[27], uint32_t* owner_out, float* dist_out) {
     uint32_t o = s.owner[v];
     float d = s.dist[v];
 #if defined(F3DS_EXP_CLAIM_NOSEL)      // timing experiment: no candidate search at all (wrong results)
-    { uint32_t x = 0; for (int k = 0; k < 27; ++k) x |= cand[k]; *owner_out = x == 0xFFFFFFFFu ? 1u : o; *dist_out = d; return; }
+    { uint32_t z = 0; for (int k = 0; k < 27; ++k) z |= x[k]; *owner_out = z == 0x7FFFFFFFu ? 1u : o; *dist_out = d; return; }
 #endif
     float vrow[12];
     a_load_row(s.vf + (size_t)v * 12, vrow);
     uint32_t last = 0;
     for (;;) {
-        uint32_t g = 0xFFFFFFFFu;     // smallest candidate label above `last`
-        for (int k = 0; k < 27; ++k) {
-            const uint32_t gu = cand[k];
-            if (gu > last && gu < g) g = gu;
-        }
-        if (g == 0xFFFFFFFFu) break;
+        const uint32_t y = a_next_label(x, F3DS_OWNR_RTRUE + last + 1u);       // smallest offering label above `last`
+        if (y >= F3DS_NO_NEXT) break;
+        const uint32_t g = y + last + 1u;
         last = g;
         if (g == o) continue;          // neighbor_voxel.owner_ == this
 #if defined(F3DS_EXP_CLAIM_NODIST)     // timing experiment: candidates searched, no distance evaluated (wrong results)
@@ -362,9 +364,10 @@ F3DS_HD void a_claim(const SweepView& s, const uint32_t* ownR, int v, uint32_t* 
     for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, v, k);
     for (int k = 0; k < 27; ++k) {
         const uint32_t x = ownR[nu[k] >= 0 ? nu[k] : v];               // unconditional loads, see a_eval_R
-        cand[k] = (nu[k] >= 0 && (x & F3DS_OWNR_RTRUE)) ? (x & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
+        cand[k] = nu[k] >= 0 ? x : 0u;
     }
-    if (!ghosts) { a_claim_cand(s, v, cand, owner_out, dist_out); return; }
+    if (!ghosts) { a_claim_words(s, v, cand, owner_out, dist_out); return; }
+    for (int k = 0; k < 27; ++k) cand[k] = (cand[k] & F3DS_OWNR_RTRUE) ? (cand[k] & 0x7fffffffu) : 0u;      // helper that offers v through leaf u (0 = none)
     uint32_t o = s.owner[v];
     float d = s.dist[v];
     float vrow[12];

@@ -1039,7 +1039,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_seed_cells(c, 3 * maxsd, maxsd); })) || (rc = flush_sync(b))) return rc;
     for (f3ds_ctx* c : b.fr) { c->C = c->h_dc->n_cells; c->res.n_seed_cells = c->C; }
     if ((rc = for_frames(b, seg_seeds)) || (rc = flush_sync(b))) return rc;
-    for (f3ds_ctx* c : b.fr) { c->S0 = c->h_dc->n_seeds; c->res.n_seeds = c->S0; }
+    for (f3ds_ctx* c : b.fr) { c->S0 = c->h_dc->n_seeds; c->res.n_seeds = c->S0; if (c->S0 >= 0x3FFFFFFFu) return F3DS_ERR_UNSUPPORTED; }      // (labels below 2^30: f3ds_algo.h, a_next_label)
     stage_mark(b, 3);
     // ---- stage 3: sweeps
     if ((rc = for_frames(b, seg_sweeps)) || (rc = flush(b))) return rc;
