@@ -232,13 +232,14 @@ F3DS_HD F3DS_NOINLINE bool a_eval_R_chain(const SweepView& s, int w0, unsigned c
         }
     }
 }
-F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned char tag, int* overflow) {
+F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned char tag, int* overflow, bool ghost_near = true) {      // ghost_near = false: the caller knows that no ghost leaf sits on w or around it
     const unsigned char T = (unsigned char)(tag << 2);
     {
         const unsigned char m0 = memo[w];
         if ((m0 & 0xFC) == T) return (m0 & 3) == F3DS_R_TRUE;
     }
-    if (*s.n_ghosts != 0u) return a_eval_R_chain(s, w, memo, tag, overflow);     // ghost leaves: general walker
+    if (ghost_near && *s.n_ghosts != 0u) return a_eval_R_chain(s, w, memo, tag, overflow);     // ghost leaves: general walker (it looks for them at every node it visits; the
+                                                                                                  // scan below only leaves them out for w itself, where there are none)
     const uint32_t h = s.owner[w];
     const float dw = s.dist[w];
     // neighbours owned by a lower label (the only possible thieves before h's turn); every lane of a
