@@ -169,6 +169,7 @@ F3DS_HD float a_helper_dist_row(const SweepView& s, uint32_t g, const float vrow
 #define F3DS_R_PASSES 1        // grid passes of the chain walker; what is still unsettled goes to the single-workgroup tail
 #define F3DS_R_TRUE 1
 #define F3DS_R_FALSE 2
+#define F3DS_R_OPEN 3        // not settled yet, and no ghost leaf sits on the voxel or around it (written by the R pre-pass: the walker then skips its ghost-chain gathers there)
 #define F3DS_OWNR_RTRUE 0x80000000u
 // memo byte = (tag << 2) | value; tag = (sweep % 63) + 1 so that entries written in an earlier sweep
 // read as "unknown" without clearing the array (it is zeroed before sweep 0, 63, 126, ...)
@@ -198,11 +199,12 @@ F3DS_HD F3DS_NOINLINE bool a_eval_R_chain(const SweepView& s, int w0, unsigned c
         const float dw = s.dist[w];
         bool pushed = false, stolen = false;
         uint32_t g_cached = 0; bool cached_less = false;
+        const bool ghosts_w = ghosts && memo[w] != (unsigned char)(T | F3DS_R_OPEN);      // (the pre-pass vouches for the voxels it marked open)
         for (int k = slot[sp]; k < 27; ++k) {
             int u = a_nbr(s, w, k);
             if (u < 0) continue;
             // a lower helper with a ghost leaf on u always reaches w at its turn
-            if (ghosts) {
+            if (ghosts_w) {
                 for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
                     if (gg < h && a_helper_dist(s, gg, w) < dw) { stolen = true; break; }
                 if (stolen) break;
@@ -236,7 +238,8 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
     const unsigned char T = (unsigned char)(tag << 2);
     {
         const unsigned char m0 = memo[w];
-        if ((m0 & 0xFC) == T) return (m0 & 3) == F3DS_R_TRUE;
+        if ((m0 & 0xFC) == T && (m0 & 3) != F3DS_R_OPEN) return (m0 & 3) == F3DS_R_TRUE;
+        if (m0 == (unsigned char)(T | F3DS_R_OPEN)) ghost_near = false;
     }
     if (ghost_near && *s.n_ghosts != 0u) return a_eval_R_chain(s, w, memo, tag, overflow);     // ghost leaves: general walker (it looks for them at every node it visits; the
                                                                                                   // scan below only leaves them out for w itself, where there are none)
