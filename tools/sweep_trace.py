@@ -14,6 +14,6 @@ for n in ("d_sweep_begin", "d_sweep_R_round", "d_sweep_R_pre", "d_sweep_R", "d_s
     v = sorted(seq.get(n, []))
     if not v:
         continue
-    per = 48 if n == "d_sweep_R_round" else 16
+    per = {"d_sweep_R_round": 42, "d_claim_mark": 15, "d_centroid_mark": 15}.get(n, 16)      # (sweeps 0 and 1 record no incremental launches, sweep 0 no marking pass)
     last = [round(x[1]) for x in v[-per:]]
     print("%-16s sum %6d us  %s" % (n, sum(last), last))
