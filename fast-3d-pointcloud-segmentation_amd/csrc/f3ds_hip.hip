@@ -9,7 +9,7 @@
 //                d_centroid, d_centroid_mark  
 //   4 summaries  d_sv_fill (payload rows + ordered leaf sums), d_edges, radix sort, d_edge_init,
 //                d_edge_deltas, d_lambda / d_cdf_*, d_edge_weights
-//   5 merge      d_merge_cw_t<2 or 8 waves, LDS residency> (one persistent workgroup per frame), d_merge (global memory)
+//   5 merge      d_merge_cw_t<2, 4 or 8 waves, LDS residency> (one persistent workgroup per frame), d_merge (global memory)
 //   6 labels     d_relabel (union-find relabel in LDS + per-point label write; d_region_ids + d_point_labels beyond 12 k supervoxels)
 // Every frame RECORDS its kernel calls; flush() zips the records of a batch into one dispatch per kernel (grid.y = frame).
 //
@@ -236,6 +236,9 @@ int pregrow_scratch(f3ds_ctx* c) {
 // gathering kernels want every wave they can get and keep the old cap (grid_wide).  Set per batch call (one host thread).
 thread_local size_t g_grid_cap = 2048;
 thread_local int g_batch_frames = 1;      // frames of the batch call this thread is running
+// batch calls inside f3ds_segment_batch right now, per device: a call whose merge dispatch shares the chip with other calls takes the 4-wave merge kernel (choose_merge_kind)
+std::atomic<int> g_batch_calls[16];
+struct BatchCallCount { int d; explicit BatchCallCount(int dev) : d(dev & 15) { g_batch_calls[d].fetch_add(1, std::memory_order_relaxed); } ~BatchCallCount() { g_batch_calls[d].fetch_sub(1, std::memory_order_relaxed); } };
 thread_local unsigned long long g_norm_t0 = ~0ull, g_norm_t1 = 0ull;      // device-clock window of the call's d_normals launch
 size_t grid_cap_for_batch(int frames) {
     static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
@@ -639,13 +642,13 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
 // d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
 bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {      // res: 2 = endpoints + keys in LDS, 1 = endpoints, 0 = neither
     memset(xl, 0, sizeof *xl);
-    const uint32_t T = (uint32_t)nw * 64u, CH = T < 256u ? T : 256u;
+    const uint32_t T = (uint32_t)nw * 64u, CH = T < 256u ? T : (nw == 4 ? 128u : 256u);
     xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
     const uint64_t fixed = (uint64_t)xl->Ecap * 4u * (uint32_t)res + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
     const uint64_t stage_off = (fixed + 15u) & ~(uint64_t)15u;
     uint64_t total = stage_off + 2u * CH * 52u + 64u;      // (+ 64: the fold loops read up to 16 rows ahead)
     xl->stage2_off = 0u; xl->spec = 0;
-    if (nw == 8) {      // staging area of an epoch's speculative second merge, switched off by F3DS_MERGE_SPEC=0
+    if (nw >= 4) {      // staging area of an epoch's speculative second merge, switched off by F3DS_MERGE_SPEC=0
         xl->stage2_off = (uint32_t)total; total += (uint64_t)MC_SP_ROWS * 52u + (uint64_t)MC_SP_TL * 8u + 64u;
         xl->spec = (getenv("F3DS_MERGE_SPEC") && !atoi(getenv("F3DS_MERGE_SPEC"))) ? 0 : 1;
     }
@@ -655,26 +658,26 @@ bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {  
 }
 // merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_CW + (8 waves ? 3 : 0) + (2 - res)
 enum MergeKind { MK_GLOBAL = 0, MK_CW = 1 };
-inline int mk_waves(int kind) { return (kind - MK_CW) >= 3 ? 8 : 2; }
+inline int mk_waves(int kind) { return (kind - MK_CW) >= 6 ? 4 : ((kind - MK_CW) >= 3 ? 8 : 2); }
 inline int mk_res(int kind) { return 2 - (kind - MK_CW) % 3; }
-// Which merge kernel a batch runs (one dispatch for all its frames): 8 waves per frame and everything that fits in LDS.  The
-// 2-wave layout (the loops are bound by instruction issue, not by lanes: two waves do the same work with a quarter of the wave
-// slots, and with a small LDS footprint several merge workgroups or other kernels' workgroups share a CU) is kept selectable:
-// F3DS_MERGE_NW=2 or F3DS_MERGE_COMPACT_MIN=<frames per call>; F3DS_MERGE_KEYS=lds|global|none (order keys and endpoints in LDS | endpoints only | neither).
-// A frame whose arrays do not fit, or with more than 65534 seeds, takes d_merge.  Other development switches:
-// F3DS_MERGE_NW=2|8, F3DS_MERGE_COMPACT_MIN=<frames>, F3DS_FORCE_GLOBAL_MERGE.
+// Which merge kernel a batch runs (one dispatch for all its frames): 8 waves per frame and everything that fits in LDS -- the shortest loop, what a lone frame or
+// a lone call wants.  A call of 16 frames or more that shares the device with other batch calls takes the 4-wave layout instead: its loop is ~20 % longer, but a
+// workgroup holds one wave slot and 250 registers per SIMD instead of two and 500, and the other calls' wide kernels run on the units the merge loops sit on
+// (+2 ... +11 % on the bench's six calls in flight over six alternating runs on three boxes; two waves: longer still, no gain).  Results are identical whatever
+// runs.  F3DS_MERGE_KEYS=lds|global|none (order keys and endpoints in LDS | endpoints only | neither) and the 2-wave layout stay selectable.
+// A frame whose arrays do not fit, or with more than 65534 seeds, takes d_merge.  Development switches:
+// F3DS_MERGE_NW=2|4|8, F3DS_MERGE_COMPACT_MIN=<frames> (2 waves from that many frames), F3DS_FORCE_GLOBAL_MERGE.
 int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
     if (force_global || getenv("F3DS_FORCE_GLOBAL_MERGE")) return MK_GLOBAL;
     const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
-    // default: never -- with six calls in flight both widths give the same throughput (2 140-2 280 vs 2 190-2 200 Mpoints/s) and the
-    // 8-wave launch of a call is over in 50 ms instead of 83
     const size_t compact_min = e_min ? (size_t)atol(e_min) : (size_t)-1;
-    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : 8) : (fr.size() >= compact_min ? 2 : 8);
-    const int first = e_keys ? (!strcmp(e_keys, "lds") ? 2 : (!strcmp(e_keys, "global") ? 1 : 0)) : (nw == 8 ? 2 : 1);
+    const bool shared = fr.size() >= 16 && g_batch_calls[fr[0]->device & 15].load(std::memory_order_relaxed) >= 2;
+    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : (atoi(e_nw) == 4 ? 4 : 8)) : (fr.size() >= compact_min ? 2 : (shared ? 4 : 8));
+    const int first = e_keys ? (!strcmp(e_keys, "lds") ? 2 : (!strcmp(e_keys, "global") ? 1 : 0)) : (nw >= 4 ? 2 : 1);
     for (int res = first; res >= (e_keys ? first : 0); --res) {
         bool ok = true;
         for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, res, &t)) { ok = false; break; } }
-        if (ok) return MK_CW + (nw == 8 ? 3 : 0) + (2 - res);
+        if (ok) return MK_CW + (nw == 8 ? 3 : (nw == 4 ? 6 : 0)) + (2 - res);
     }
     return MK_GLOBAL;
 }
@@ -756,6 +759,9 @@ int seg_merge(f3ds_ctx* c) {
         case MK_CW + 3: rec<d_merge_cw_t<8, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         case MK_CW + 4: rec<d_merge_cw_t<8, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         case MK_CW + 5: rec<d_merge_cw_t<8, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 6: rec<d_merge_cw_t<4, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 7: rec<d_merge_cw_t<4, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_CW + 8: rec<d_merge_cw_t<4, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         default: rec<d_merge>(c, 1u, 0u, c->mdev);
     }
     return F3DS_OK;
@@ -969,6 +975,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     const auto t0 = std::chrono::steady_clock::now();
     g_t_wait = 0; g_t_launch = 0;
     HIPCHECK(hipSetDevice(ctxs[0]->device));
+    BatchCallCount in_flight(ctxs[0]->device);
     Batch b;
     b.owner = ctxs[0]; b.st = ctxs[0]->stream;
     BatchStreamLease lease;
