@@ -257,6 +257,13 @@ def main():
     except Exception as e:      # noqa
         parity = {"error": repr(e)}
 
+    merge_layouts = {}      # which merge kernel every call group's last batch call ran (before the lone frames below overwrite it)
+    for grp in ctxs[:ngroups]:
+        try:
+            lay = grp[0].merge_layout()
+            merge_layouts[lay] = merge_layouts.get(lay, 0) + 1
+        except Exception:
+            pass
     # single-frame latency (one stream, nothing else in flight) for the record
     barrier()
     tl = time.perf_counter()
@@ -275,7 +282,12 @@ def main():
         # device clock, first workgroup started .. last one ended -- an event pair around that dispatch also counts the 10-15 ms it waits at the head of its
         # queue for a compute unit with 72 KB of LDS free, which a kernel trace does not); the other stages are sequences of many launches of several
         # kernels (their per-kernel split is in profiles/r3_kernel_stats*.csv) and are reported as stages below.
-        KERNELS = {5: ("k_batched<d_merge_cw_t<8,2>>", "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals>", "neighbours+normals", "d_normals")}
+        # (which merge kernel: the library takes the 4-wave layout for a call that shares the device with other batch calls, the 8-wave one otherwise; asked of every
+        # call group's context after the timed region (above) -- what its LAST call ran -- and the most frequent answer names the kernel)
+        layouts = merge_layouts
+        lay = max(layouts, key=layouts.get) if layouts else (8, 2)
+        merge_name = "k_batched<d_merge_cw_t<%d,%d>>" % lay if lay[0] else "k_batched<d_merge>"
+        KERNELS = {5: (merge_name, "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals>", "neighbours+normals", "d_normals")}
         dom = max(KERNELS, key=lambda j: stage_ms[j])
         dom_ms = mean_stage[dom]
         alg_launch = ALG_BYTES_PER_POINT * npts * frames_per_launch
@@ -308,6 +320,7 @@ def main():
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                     "algorithmic_bytes_per_launch": int(alg_launch),
                     "dominant_by": "total launch time measured in this run: %s" % ", ".join("%s %.1f ms" % (KERNELS[j][2], stage_ms[j]) for j in KERNELS),
+                    "merge_layouts_last_call": {"%d waves, residency %d" % k: v for k, v in layouts.items()},
                     "whole_path": whole,
                     "stages": stages,
                     "stage_ms_per_call": {STAGES[i]: round(mean_stage[i], 4) for i in range(7)}}

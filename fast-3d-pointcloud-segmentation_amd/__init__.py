@@ -361,6 +361,12 @@ class Context:
         _check(self.lib, self.lib.f3ds_get_voxel_cloud(self.handle, xyz.ctypes.data, lab.ctypes.data, rgba.ctypes.data, n.value, ctypes.byref(n)))
         return xyz, lab, rgba
 
+    def merge_layout(self):
+        """(waves per frame, per-edge arrays in LDS) of the merge kernel the last cluster stage ran; (0, 0) = d_merge (F3DS_DBG_MERGE_LAYOUT)."""
+        nb = ctypes.c_size_t(); buf = np.zeros(2, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 20, buf.ctypes.data, 8, ctypes.byref(nb)))
+        return int(buf[0]), int(buf[1])
+
     def debug(self, name):
         nb = ctypes.c_size_t()
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, DBG[name], None, 0, ctypes.byref(nb)))

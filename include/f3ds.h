@@ -166,7 +166,10 @@ enum {
     F3DS_DBG_EDGE_WEIGHTS = 16,   /* E f32 initial weights                                      */
     F3DS_DBG_MERGES = 17,         /* n_merges x 3 u32: a, b, weight bits                        */
     F3DS_DBG_VOXEL_REGION = 18,   /* V u32 final region id per voxel (F3DS_NO_LABEL = none)     */
-    F3DS_DBG_SV_REGION = 19       /* S u32 surviving label each supervoxel ended in             */
+    F3DS_DBG_SV_REGION = 19,      /* S u32 surviving label each supervoxel ended in             */
+    F3DS_DBG_MERGE_LAYOUT = 20    /* 2 u32: which merge kernel the last cluster stage ran -- waves per frame (2, 4, 8; 0 = d_merge,
+                                     everything in global memory) and what it kept in LDS (2 = order keys + endpoints, 1 = endpoints,
+                                     0 = neither).  Diagnostics (bench.py names the kernel it timed): results do not depend on it */
 };
 int f3ds_get_debug(f3ds_ctx* ctx, int what, void* dst, size_t cap_bytes, size_t* bytes_out);
 

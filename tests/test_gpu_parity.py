@@ -816,6 +816,45 @@ def test_relabel_as_two_kernels_matches_too(P, oracle, monkeypatch, cap):
 
 
 @pytest.mark.gpu
+def test_merge_layout_follows_what_else_is_on_the_device(P, oracle):
+    """choose_merge_kind: a lone frame and a lone batch call run the 8-wave merge loop; batch calls of 16 frames or more that overlap on one device
+    take the 4-wave one.  Labels are the oracle's either way (F3DS_DBG_MERGE_LAYOUT is diagnostics only)."""
+    import threading
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.1)
+    frames = [P.synth_frame(0, 4100 + i, 200, 150, 30) for i in range(4)]
+    want = [oracle.segment(f, prm)[1] for f in frames]
+    ctx = P.Context(0)
+    assert np.array_equal(ctx.segment(frames[0], prm), want[0])
+    assert ctx.merge_layout() == (8, 2)
+    groups = [[P.Context(0) for _ in range(16)] for _ in range(3)]
+    labs = P.segment_batch(groups[0], [frames[i % 4] for i in range(16)], prm)
+    assert all(np.array_equal(labs[i], want[i % 4]) for i in range(16))
+    assert groups[0][0].merge_layout() == (8, 2)          # nothing else was running
+    seen, errors = [], []
+
+    def worker(g):
+        try:
+            for it in range(6):
+                labs = P.segment_batch(groups[g], [frames[(i + g) % 4] for i in range(16)], prm)
+                assert all(np.array_equal(labs[i], want[(i + g) % 4]) for i in range(16)), (g, it)
+                seen.append(groups[g][0].merge_layout())
+        except Exception as e:      # noqa
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(g,)) for g in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert set(seen) <= {(4, 2), (8, 2)} and (4, 2) in seen, seen      # (a call that happens to reach its merge stage alone keeps 8 waves)
+    for grp in groups:
+        for c in grp:
+            c.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_mixed_frame_sizes_on_concurrent_contexts_keep_their_state(P, oracle):
     """Scratch is sized by device-wide high-water marks.  A context must never lose frame state because ANOTHER
     context (another thread) met a larger frame: ENSURE only regrows a buffer that is too small for the request, and buffers
