@@ -287,7 +287,7 @@ def main():
         layouts = merge_layouts
         lay = max(layouts, key=layouts.get) if layouts else (8, 2)
         merge_name = "k_batched<d_merge_cw_t<%d,%d>>" % lay if lay[0] else "k_batched<d_merge>"
-        KERNELS = {5: (merge_name, "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals>", "neighbours+normals", "d_normals")}
+        KERNELS = {5: (merge_name, "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals_t<%d>>" % (256 if nbatch >= 16 else 384), "neighbours+normals", "d_normals_t")}      # (256 threads per tile in calls of >= 16 frames)
         dom = max(KERNELS, key=lambda j: stage_ms[j])
         dom_ms = mean_stage[dom]
         alg_launch = ALG_BYTES_PER_POINT * npts * frames_per_launch
@@ -300,7 +300,8 @@ def main():
                 break
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            traffic = int(pm["kernels"][KERNELS[dom][2]]["hbm_bytes_per_frame"] * frames_per_launch)
+            pk = pm["kernels"]
+            traffic = int((pk.get(KERNELS[dom][2]) or pk[KERNELS[dom][2].replace("_t", "")])["hbm_bytes_per_frame"] * frames_per_launch)
             path_traffic = int(pm["whole_path_hbm_bytes_per_frame"])          # upper bound (every read request taken as 128 bytes)
             path_traffic_min = int(pm["whole_path_hbm_bytes_per_frame_min"])  # lower bound (64-byte requests in the kernels that gather)
         except Exception:

@@ -3,7 +3,7 @@
 // Stage map (kernel functors d_<name> live in f3ds_kernels.inc; reference citations are in include/f3ds.h,
 // csrc/f3ds_numerics.h, csrc/f3ds_algo.h):
 //   0 voxelise   d_bbox -> d_grid -> d_keys -> radix sort -> d_heads/scan/d_segstart -> d_point_gather -> d_voxel_accum
-//   1 neighbours d_neighbors (hash probe of the 27 cells), d_normals (two-ring ordered covariance, LDS tile)
+//   1 neighbours d_neighbors (hash probe of the 27 cells), d_normals_t<384 | 256 threads> (two-ring ordered covariance, LDS tile)
 //   2 seeds      d_chunkbox, d_seed_grow, d_seed_keys, radix sort, d_cell_hash, d_seed_nn, d_seed_filter
 //   3 sweeps     per sweep: d_sweep_begin, d_sweep_R_round x4 | d_sweep_R_pre + d_sweep_R, d_sweep_claim, d_claim_mark,
 //                d_centroid, d_centroid_mark  
@@ -482,8 +482,13 @@ int seg_normals(f3ds_ctx* c) {
     static const uint32_t budget = 0u;      // (the tile loop is compiled in with make EXTRA=-DF3DS_NORMALS_LOOP only)
 #endif
     const uint32_t share = budget ? std::max(2u, budget / (uint32_t)g_batch_frames) : nt;
-    rec<d_normals>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots,
-                   (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0));
+    // 256 threads per tile for the calls of a batch pipeline (their workgroups fit beside the 4-wave merge loops of the other calls), 384 otherwise (kernels.inc)
+    const int nthr_env = getenv("F3DS_NORMALS_THREADS") ? atoi(getenv("F3DS_NORMALS_THREADS")) : 0;
+    const uint32_t holes = (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0);
+    if (nthr_env ? nthr_env == 256 : g_batch_frames >= 16)
+        rec<d_normals_t<256>>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots, holes);
+    else
+        rec<d_normals_t<384>>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots, holes);
     return F3DS_OK;
 }
 // stage 2a: seed grid growth

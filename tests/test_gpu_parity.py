@@ -931,6 +931,29 @@ def test_cli_gpus_unreadable_file_and_bench_flag(P, oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threads", ["256", "384"])
+def test_voxel_normals_kernel_widths_agree_with_the_golden_normals(P, monkeypatch, threads):
+    """d_normals_t<384> builds a tile's tables with six waves (lone frames, small calls), d_normals_t<256> with four (calls of 16 frames or more:
+    a four-wave workgroup fits on a unit beside another call's merge loop).  Each forced here (F3DS_NORMALS_THREADS, read per call) on golden
+    cases -- small noisy frames whose tiles overflow the one-ring / two-ring tables take the global-memory path inside the same launch -- and on the
+    1M-point frame: normals, and what the sweeps make of the tile tables the kernel writes for them."""
+    monkeypatch.setenv("F3DS_NORMALS_THREADS", threads)
+    big = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
+    ctx = P.Context(0)
+    for n in ["rgbd_320x240_ghosts", "rgbd_320x240_large_supervoxels", "fixture_launch_flags", "fused_200k_nan_lambda", "rgbd_160x120_rgb_metric"]:
+        lab = ctx.segment(case_points(P, n), case_params(P, n))
+        assert sha_of(lab) == GOLD[n]["labels_sha256"], n
+        for w in ("VOXEL_NORMAL", "VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID"):
+            assert sha_of(ctx.debug(w)) == GOLD[n]["sha256"][w], (n, w)
+    e = big["config5_seed1061"]
+    lab = ctx.segment(P.synth_frame(*e["synth"]), P.launch_params(**e["params"]))
+    assert sha_of(lab) == e["labels_sha256"]
+    for w in ("VOXEL_SVLABEL", "MERGES"):
+        assert sha_of(ctx.debug(w)) == e["sha256"][w], w
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(F3DS_SWEEP_TILES="0"), dict(F3DS_SWEEP_TILE_HOLES="3"), dict(F3DS_SWEEP_TILE_HOLES="2", F3DS_INC_SHIFT="32")],
                          ids=["global-gathers", "every-third-tile-global", "holes-and-always-incremental"])
 def test_lds_tiled_sweeps_equal_the_global_gather_sweeps(P, env):
