@@ -367,6 +367,14 @@ class Context:
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, 20, buf.ctypes.data, 8, ctypes.byref(nb)))
         return int(buf[0]), int(buf[1])
 
+    def tile_list_lengths(self):
+        """Length of every 128-voxel tile's one-ring list; 0xFFFFFFFF = the tile overflowed the LDS tables (F3DS_DBG_TILE_LIST_LEN)."""
+        nb = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 21, None, 0, ctypes.byref(nb)))
+        buf = np.zeros(nb.value // 4, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 21, buf.ctypes.data, nb.value, ctypes.byref(nb)))
+        return buf
+
     def debug(self, name):
         nb = ctypes.c_size_t()
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, DBG[name], None, 0, ctypes.byref(nb)))

@@ -1341,6 +1341,7 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
     if (what != F3DS_DBG_GRID && !c->have_frame) return F3DS_ERR_LOGIC;
     switch (what) {
         case F3DS_DBG_GRID: { HIPCHECK(hipMemcpy(c->h_grid, c->d_grid, sizeof(GridInfo), hipMemcpyDeviceToHost)); double g[5] = {c->h_grid->min[0], c->h_grid->min[1], c->h_grid->min[2], c->h_grid->res, (double)c->h_grid->depth}; put(g, sizeof g); break; }
+        case F3DS_DBG_TILE_LIST_LEN: if ((rc = fetch(c, c->tile_n1, (size_t)(V + NT_TILE - 1) / NT_TILE, u))) return rc; put(u.data(), u.size() * 4); break;
         case F3DS_DBG_MERGE_LAYOUT: { const uint32_t w[2] = {c->merge_kind == MK_GLOBAL ? 0u : (uint32_t)mk_waves(c->merge_kind), c->merge_kind == MK_GLOBAL ? 0u : (uint32_t)mk_res(c->merge_kind)}; put(w, 8); break; }
         case F3DS_DBG_VOXEL_KEYS: if ((rc = fetch(c, c->vkey, (size_t)V * 3, u))) return rc; put(u.data(), u.size() * 4); break;
         case F3DS_DBG_VOXEL_COUNT: if ((rc = fetch(c, c->vcount, V, u))) return rc; put(u.data(), u.size() * 4); break;
