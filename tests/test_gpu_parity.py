@@ -948,6 +948,10 @@ def test_voxel_normals_kernel_widths_agree_with_the_golden_normals(P, monkeypatc
     e = big["config5_seed1061"]
     lab = ctx.segment(P.synth_frame(*e["synth"]), P.launch_params(**e["params"]))
     assert sha_of(lab) == e["labels_sha256"]
+    tl = ctx.tile_list_lengths()              # F3DS_DBG_TILE_LIST_LEN: one entry per 128-voxel tile, a one-ring list of at most 448 voxels or "overflowed"
+    assert len(tl) == (ctx.result.n_voxels + 127) // 128
+    fits = tl[tl != 0xFFFFFFFF]
+    assert len(fits) > 0.9 * len(tl) and fits.min() >= 1 and fits.max() <= 448
     for w in ("VOXEL_SVLABEL", "MERGES"):
         assert sha_of(ctx.debug(w)) == e["sha256"][w], w
     ctx.close()
