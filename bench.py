@@ -20,21 +20,28 @@ output of a step is ONE RCCL gather of the step's [64, 1M] uint32 label block to
 step order from a dedicated thread while later steps run.
 
 The JSON line also carries
-  value_host_io -- the same loop with the frames in pinned host memory and the labels delivered to
-                  pinned host memory (PCIe both ways inside the timed region: what SURVEY.md 8d
-                  defines); `value` itself is the HBM-resident rate;
-  roofline     -- dominant kernel by MEASURED device time: two kernels of the path are one launch per
-                  call and bracketed by HIP events on the call's stream inside libf3ds (the merge loop,
-                  the voxel normals); the one with the larger total is named.  achieved = 20 B/point x
-                  points per launch / mean launch duration, against the 8 TB/s HBM3E peak; `stages` =
-                  the same figure for every stage of a call (sequences of many launches); `whole_path`
-                  = the timed region as a whole, with the PMC-measured HBM traffic of all kernels;
-  cpu_baseline -- the CPU oracle (kind "port": the reference needs PCL/OpenCV and cannot be built
-                  here) on the same workload, rank 0 at N=1 only: one frame on one core (the reference
-                  is single-threaded), and `frames_parallel`: the 64-frame batch, one frame per core,
-                  over the host's cores (count stated).
-A label hash that differs from the oracle's committed hashes voids the run: `value` is null and the
-exit code 1.
+  value              -- whole-job Mpoints/s with the frames resident in HBM when the timed region starts and the
+                        labels left in HBM (the bench contract of this build: a PCIe-inclusive rate is never `value`);
+                        `value_hbm_resident` repeats it under an explicit name;
+  value_host_io      -- the metric as SURVEY.md 8d words it (host buffer in -> per-point labels in a host buffer):
+                        the same loop with the frames in pinned host memory and the labels delivered to pinned host
+                        memory, PCIe both ways inside the timed region; `value_survey_8d` repeats its number at top level;
+  config5_batch_latency_ms -- BASELINE config 5 as literally stated, from an idle GPU: wall time of ONE batch of 64 frames
+                        as one call on one GPU (the N=1 shape) and of ONE call of 8 frames (what each GPU runs at N=8);
+  roofline           -- the dominant kernel is the merge loop (k_batched<d_merge_*>: first by total kernel time in the
+                        rocprofv3 trace of this same command, profiles/r4_kernel_stats.csv); its launch duration is
+                        measured live by a pair of HIP events around that one dispatch on the call's stream inside
+                        libf3ds (f3ds_result.ms_stage[5]) and averaged over the timed region's calls.  achieved =
+                        20 B/point x points per launch / mean launch duration, against the 8 TB/s HBM3E peak;
+                        `stages` = the same figure for every stage of a call (sequences of many launches);
+                        `whole_path` = the timed region as a whole, with the PMC-measured HBM traffic of all kernels;
+  cpu_baseline       -- the CPU oracle (kind "port": the reference needs PCL/OpenCV and cannot be built here) on the
+                        same workload, rank 0 at N=1 only: one frame on one core (the reference is single-threaded)
+                        through the libm-linked build of the oracle -- what a PCL/OpenCV build calls; its labels are
+                        first checked against the shared-math build's, whose time is reported beside it --, and
+                        `frames_parallel`: the 64-frame batch, one frame per core, over the host's cores (count stated).
+A label hash that differs from the oracle's committed hashes voids the run: `value` is null and the exit code 1; so
+does any what-if environment that changes results or the measured configuration (F3DS_BENCH_THRESHOLD, a +whatif library).
 """
 import argparse
 import json
@@ -117,6 +124,8 @@ def main():
 
     P = importlib.import_module("fast-3d-pointcloud-segmentation_amd")
     B = importlib.import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    P.check_library_is_current()       # a stale prebuilt libf3ds.so (built from other sources than those beside it) is not measured
+    lib_text = P.library_stamp()[1]
     prm = P.launch_params(voxel_res=0.008, seed_res=0.08)          # -v 0.008 -s 0.08 --AL --CVX -t 0.2
     if os.environ.get("F3DS_BENCH_THRESHOLD"):                    # development only: what-if runs (the JSON line then names the threshold)
         prm.threshold = float(os.environ["F3DS_BENCH_THRESHOLD"])
@@ -236,7 +245,7 @@ def main():
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")))
         blk = label_blocks[(args.steps - 1) % n_blocks].cpu().numpy()
         checked, bad = 0, []
-        if npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD") and not os.environ.get("F3DS_FAKE_MERGE"):      # (development what-if runs change the labels)
+        if npts == 1000 * 1000 and not os.environ.get("F3DS_BENCH_THRESHOLD"):      # (another threshold gives other labels: such a run is void anyway, below)
             with ThreadPoolExecutor(16) as ex:
                 keys = ["config5_seed%d" % sd for sd in seeds]
                 have = [i for i in range(FPS) if keys[i] in gold]
@@ -271,6 +280,23 @@ def main():
         ctxs[0][0].segment(frames_dev[s].data_ptr(), prm, labels_out=label_blocks[0][0].data_ptr(), n=npts, on_device=True)
     latency_ms = (time.perf_counter() - tl) / 3 * 1e3
     res = ctxs[0][0].result
+    # BASELINE config 5 as literally stated ("a batch of 64 frames sharded over 8 GPUs"), from an idle GPU: ONE batch of 64 frames as one
+    # call on this GPU (N = 1), and ONE call of 8 frames (each GPU's share at N = 8); frames and labels in HBM; median of 3 after one untimed call
+    def one_call_ms(k):
+        times = []
+        for rep_ in range(4):
+            barrier()
+            t1 = time.perf_counter()
+            P.segment_batch(ctxs[0][:k], [frames_dev[f].data_ptr() for f in range(k)], prm, labels_out=[label_blocks[0][f].data_ptr() for f in range(k)], n=[npts] * k, on_device=True)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t1) * 1e3)
+        return sorted(times[1:])[1]
+    batch_latency = None
+    if nbatch >= FPS:
+        b64, b8 = one_call_ms(FPS), one_call_ms(8)
+        batch_latency = {"one_batch_of_64_frames_one_gpu": round(b64, 3), "one_call_of_8_frames": round(b8, 3),
+                         "mpoints_per_s_64": round(FPS * npts / b64 / 1e3, 1), "mpoints_per_s_8": round(8 * npts / b8 / 1e3, 1),
+                         "what": "wall time of ONE f3ds_segment_batch call from an idle GPU, frames and labels resident in HBM, median of 3: config 5's batch on one GPU, and the 8 frames each GPU runs when the 64 are sharded over 8 GPUs (the RCCL gather of 8 x 4 MB per peer is not in it)"}
 
     if rank == 0:
         total_frames = args.steps * FPS
@@ -288,13 +314,15 @@ def main():
         lay = max(layouts, key=layouts.get) if layouts else (8, 2)
         merge_name = "k_batched<d_merge_cw_t<%d,%d>>" % lay if lay[0] else "k_batched<d_merge>"
         KERNELS = {5: (merge_name, "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals_t<%d>>" % (256 if nbatch >= 16 else 384), "neighbours+normals", "d_normals_t")}      # (256 threads per tile in calls of >= 16 frames)
-        dom = max(KERNELS, key=lambda j: stage_ms[j])
+        # the merge loop is the first kernel by total time in the kernel trace of this command (profiles/r4_kernel_stats.csv), and the one kernel whose
+        # event pair brackets exactly one dispatch; the voxel-normal launch's pair is reported beside it (dominant_by), it includes that dispatch's wait for a unit
+        dom = 5
         dom_ms = mean_stage[dom]
         alg_launch = ALG_BYTES_PER_POINT * npts * frames_per_launch
         achieved = alg_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = path_traffic = path_traffic_min = None
         pmc_file = None
-        for cand in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):      # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
+        for cand in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):      # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
             if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand
                 break
@@ -320,7 +348,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                     "algorithmic_bytes_per_launch": int(alg_launch),
-                    "dominant_by": "total launch time measured in this run: %s" % ", ".join("%s %.1f ms" % (KERNELS[j][2], stage_ms[j]) for j in KERNELS),
+                    "dominant_by": "first kernel by total time in the rocprofv3 kernel trace of this command (profiles/); HIP-event totals of this run: %s" % ", ".join("%s %.1f ms" % (KERNELS[j][2], stage_ms[j]) for j in KERNELS),
+                    "timer": "hipEventRecord pair around the one merge dispatch of every call, on the call's stream (f3ds_result.ms_stage[5]), mean over the timed region's %d calls" % calls_done[0],
                     "merge_layouts_last_call": {"%d waves, residency %d" % k: v for k, v in layouts.items()},
                     "whole_path": whole,
                     "stages": stages,
@@ -328,21 +357,35 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from conftest import CpuChecker
-            ora = CpuChecker(os.path.join(ROOT, "oracle", "libf3ds_oracle.so"), "f3ds_oracle")
+            import hashlib
+            # The baseline is timed on the libm-linked build of the oracle (glibc log / exp / cbrt / atan2 ...: what a real PCL / OpenCV build calls);
+            # the shared-math build (csrc/f3ds_math.h, transcendentals from IEEE basic operations so that host and device agree to the bit) is
+            # the parity checker and ~1.6x slower: its time is reported beside it, and the two label vectors must be identical.
+            ora_sm = CpuChecker(os.path.join(ROOT, "oracle", "libf3ds_oracle.so"), "f3ds_oracle")
+            ora = CpuChecker(os.path.join(ROOT, "oracle", "libf3ds_oracle_libm.so"), "f3ds_oracle")
+            ts = time.perf_counter()
+            rc_sm, olab_sm, _, oh_sm = ora_sm.segment(frames_host[0], prm)
+            sm_s = time.perf_counter() - ts
+            oh_sm.close()
             tc = time.perf_counter()
             rc, olab, ores, oh = ora.segment(frames_host[0], prm)
             cpu_s = time.perf_counter() - tc
-            assert rc == 0
+            assert rc == 0 and rc_sm == 0
+            libm_same = hashlib.sha256(olab.tobytes()).hexdigest() == hashlib.sha256(olab_sm.tobytes()).hexdigest()
             # what a user of the reference's main() waits for on top of the label path: refineSupervoxels(3) (viewer only) and a
             # second VCCS run on the label-coloured cloud (/root/reference/src/supervoxel_clustering.cpp:369-400)
             tm = time.perf_counter()
             oh.refine(3)
+            if not libm_same:
+                cpu["value"] = None; cpu["invalid"] = "the libm-linked oracle's labels differ from the shared-math oracle's on this frame"
             p0 = prm.copy(); p0.threshold = 0.0
             rc2, _, _, oh2 = ora.segment(frames_host[1], p0)
             main_s = cpu_s + time.perf_counter() - tm
             oh2.close()
             cpu = {"value": round(npts / cpu_s / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
-                   "sample": "1 frame (%d points) of the same workload through oracle/libf3ds_oracle.so, %.2f s" % (npts, cpu_s),
+                   "sample": "1 frame (%d points) of the same workload through oracle/libf3ds_oracle_libm.so (libm transcendentals), %.2f s" % (npts, cpu_s),
+                   "labels_equal_shared_math_build": libm_same,
+                   "shared_math_build": {"value": round(npts / sm_s / 1e6, 4), "seconds": round(sm_s, 2), "what": "the same frame through oracle/libf3ds_oracle.so (the bit-parity checker: transcendentals of csrc/f3ds_math.h)"},
                    "as_main_runs_it": {"value": round(npts / main_s / 1e6, 4), "seconds": round(main_s, 2),
                                        "what": "label path + refineSupervoxels(3) + a second VCCS extract (the truth cloud), as main() does per file"},
                    "note": "the port is faster than the reference would be: hash-set contains() instead of the O(E) scan, cached mean_color",
@@ -358,10 +401,21 @@ def main():
             par_s = time.perf_counter() - tp
             assert all(r == 0 for r in done)
             cpu["frames_parallel"] = {"value": round(FPS * npts / par_s / 1e6, 4), "unit": "Mpoints/s", "cores": nthr, "host_cpus": ncores, "seconds": round(par_s, 2),
-                                      "sample": "the %d frames of one step, one frame per core on %d threads through oracle/libf3ds_oracle.so (label path only)" % (FPS, nthr)}
+                                      "sample": "the %d frames of one step, one frame per core on %d threads through oracle/libf3ds_oracle_libm.so (label path only)" % (FPS, nthr)}
         invalid = None
+        what_if = {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_FAKE_MERGE", "F3DS_FAKE_MERGE_LDS") if os.environ.get(k)}
+        if "+whatif" in lib_text:
+            what_if["library"] = lib_text
         if parity and (parity.get("error") or parity.get("mismatches_all_ranks")):
             invalid = "labels differ from the oracle's committed hashes" if not parity.get("error") else "label check failed: " + parity["error"]
+        elif npts == 1000 * 1000 and not (parity and parity.get("frames_checked")):
+            invalid = "no frame of the timed region was checked against the oracle's hashes"
+        if npts != 1000 * 1000:
+            what_if["frame"] = "%dx%d" % (args.width, args.height)
+            invalid = None
+        if what_if:      # a run that changes results or the measured configuration is a timing experiment, never a measurement
+            invalid = "what-if run (%s): timing experiment, not a measurement%s" % (", ".join(sorted(what_if)), "; not the BASELINE workload (1000x1000-point frames)" if "frame" in what_if else "")
+        what_if_value = value
         if invalid:
             value = None
         line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3) if value is not None else None, "invalid": invalid, "unit": "Mpoints/s", "n_gpus": world,
@@ -375,8 +429,13 @@ def main():
                            "parallelism": ("%d ranks, one per GPU, every rank its own frames" % world) if world > 1 else "1 GPU",
                            "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
-                "what_if": {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_FAKE_MERGE") if os.environ.get(k)} or None,
-                "value_host_io": host_io, "labels_checked": parity, "single_frame_latency_ms": round(latency_ms, 3), "roofline": roofline, "cpu_baseline": cpu}
+                "what_if": what_if or None, "what_if_value": round(what_if_value, 3) if what_if else None,
+                "value_hbm_resident": round(value, 3) if value is not None else None,
+                "value_survey_8d": host_io["value"] if host_io else None,
+                "value_note": "`value`: frames resident in HBM, labels left in HBM (the bench contract: a PCIe-inclusive rate is never `value`); `value_survey_8d` = `value_host_io.value`: "
+                              "pinned host buffer in -> labels in a pinned host buffer, the metric as SURVEY.md 8d words it",
+                "value_host_io": host_io, "labels_checked": parity, "single_frame_latency_ms": round(latency_ms, 3), "config5_batch_latency_ms": batch_latency,
+                "library": lib_text, "roofline": roofline, "cpu_baseline": cpu}
     for grp in ctxs:
         for c in grp:
             c.close()

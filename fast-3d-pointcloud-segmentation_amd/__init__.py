@@ -98,6 +98,7 @@ def load_library(path=None):
     vp, sz, u32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)
     lib.f3ds_default_params.argtypes = [ctypes.POINTER(Params)]; lib.f3ds_default_params.restype = None
     lib.f3ds_version.restype = ctypes.c_int
+    lib.f3ds_version_string.restype = ctypes.c_char_p
     lib.f3ds_strerror.argtypes = [ctypes.c_int]; lib.f3ds_strerror.restype = ctypes.c_char_p
     lib.f3ds_last_hip_error.restype = ctypes.c_char_p
     lib.f3ds_device_count.restype = ctypes.c_int
@@ -135,6 +136,7 @@ def load_library(path=None):
     lib.f3ds_multi_collect.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_collect.restype = ctypes.c_int
     lib.f3ds_multi_reserve.argtypes = [vp, sz]; lib.f3ds_multi_reserve.restype = ctypes.c_int
     lib.f3ds_multi_gathered_labels.argtypes = [vp]; lib.f3ds_multi_gathered_labels.restype = vp
+    lib.f3ds_multi_gathered_labels_of.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_gathered_labels_of.restype = vp
     lib.f3ds_multi_last_error.restype = ctypes.c_char_p
     lib.f3ds_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_stream_create.restype = ctypes.c_int
     lib.f3ds_stream_destroy.argtypes = [vp]; lib.f3ds_stream_destroy.restype = None
@@ -153,6 +155,40 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def source_stamp():
+    """First 16 hex digits of the SHA-256 over the library's sources as csrc/Makefile hashes them (every *.hip *.inc *.h *.cpp of
+    csrc/ but the generated stamp header, in byte-wise name order, then include/f3ds.h and include/f3ds_clustering.hpp)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    names = sorted(os.path.basename(f) for pat in ("*.hip", "*.inc", "*.h", "*.cpp") for f in glob.glob(os.path.join(csrc, pat)))
+    files = [os.path.join(csrc, n) for n in names if n != "f3ds_build_stamp.h"]
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files += [os.path.join(inc, "f3ds.h"), os.path.join(inc, "f3ds_clustering.hpp")]
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def library_stamp(lib=None):
+    """The stamp the loaded libf3ds.so was built from (f3ds_version_string: 'f3ds 1.1.0 src:<stamp>[ +whatif]')."""
+    text = (lib or load_library()).f3ds_version_string().decode()
+    return text.split("src:")[1].split()[0], text
+
+
+def check_library_is_current(lib=None):
+    """Raise if the loaded libf3ds.so was not built from the sources beside it (a stale prebuilt .so travels to the GPU box with the
+    snapshot; measuring or testing it would describe some other code).  Skipped when F3DS_LIB points at another build on purpose."""
+    if os.environ.get("F3DS_LIB"):
+        return
+    have, text = library_stamp(lib)
+    want = source_stamp()
+    if have != want:
+        raise ImportError("libf3ds.so is stale: built from sources %s, the tree holds %s (%s) -- rebuild with make -C %s" % (have, want, text, os.path.join(_HERE, "csrc")))
 
 
 (OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_DEPTH, ERR_LOGIC, ERR_RANGE, ERR_UNSUPPORTED, ERR_IO, ERR_EQ_BIN,

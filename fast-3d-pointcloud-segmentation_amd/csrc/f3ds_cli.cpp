@@ -208,23 +208,24 @@ int main(int argc, char** argv) {
         if (rc) { fprintf(stderr, "f3ds_multi_create(%d GPUs): %s %s %s\n", G, f3ds_strerror(rc), f3ds_last_hip_error(), f3ds_multi_last_error()); return 1; }
         std::vector<std::vector<uint32_t>> labels[2];
         for (auto& l : labels) l.assign((size_t)chunk, std::vector<uint32_t>(npts));
+        std::vector<f3ds_result> res[2]; res[0].resize((size_t)chunk); res[1].resize((size_t)chunk);      // written by the driver's threads until a batch is collected: they outlive run()
         auto run = [&](int total, double* seconds, f3ds_result* last) -> int {
             const auto t0 = std::chrono::steady_clock::now();
             int tickets[2] = {-1, -1}, sub = 0, col = 0;
             const int nchunks = (total + chunk - 1) / chunk;
-            std::vector<f3ds_result> res[2]; res[0].resize((size_t)chunk); res[1].resize((size_t)chunk);
+            auto drain = [&](int rc_) { for (; col < sub; ++col) (void)f3ds_multi_collect(mg, tickets[col & 1]); return rc_; };      // error path: nothing of this run stays in flight
             while (col < nchunks) {
                 if (sub < nchunks && sub - col < 2) {
                     const int k0 = sub * chunk, k = std::min(chunk, total - k0), s = sub & 1;
                     std::vector<const void*> pp; std::vector<size_t> cnt; std::vector<uint32_t*> lp;
                     for (int i = 0; i < k; ++i) { pp.push_back(pts[(size_t)((k0 + i) % distinct)].data()); cnt.push_back(npts); lp.push_back(labels[s][(size_t)i].data()); }
                     const int r = f3ds_multi_submit(mg, pp.data(), cnt.data(), k, &prm, lp.data(), res[s].data(), &tickets[s]);
-                    if (r) return r;
+                    if (r) return drain(r);
                     sub++;
                     continue;
                 }
                 const int r = f3ds_multi_collect(mg, tickets[col & 1]);
-                if (r) return r;
+                if (r) { col++; return drain(r); }
                 if (last) *last = res[col & 1][0];
                 col++;
             }

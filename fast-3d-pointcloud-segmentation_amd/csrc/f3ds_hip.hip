@@ -96,6 +96,27 @@ struct Cmd { LaunchFn fn; uint32_t gx, lds, bytes, off; };
 // F3DS_INC_SHIFT=-1 turns the skipping off (every sweep evaluates every voxel), 32 forces it always.
 const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e ? atoi(e) : 6; }();
 
+// Development / test switches (none is needed in production and none changes results).  The environment is read ONCE per entry
+// call of the library (f3ds_segment_batch, f3ds_recluster, f3ds_refine_supervoxels) into this per-thread struct -- not per frame on the hot path,
+// where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
+struct Switches {
+    bool split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
+    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0; size_t merge_compact_min = (size_t)-1; long relabel_lds_cap = -1;
+    void read() {
+        auto on = [](const char* n) { return getenv(n) != nullptr; };
+        auto num = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
+        split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
+        force_global_merge = on("F3DS_FORCE_GLOBAL_MERGE"); no_stream_pool = on("F3DS_NO_STREAM_POOL"); sort_pairs = on("F3DS_SORT_PAIRS");
+        host_prof = on("F3DS_HOST_PROF"); trace_err = on("F3DS_TRACE_ERR");
+        normals_threads = (int)num("F3DS_NORMALS_THREADS", 0); tile_holes = (uint32_t)num("F3DS_SWEEP_TILE_HOLES", 0);
+        { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 2 ? 2 : (v == 4 ? 4 : (v ? 8 : 0)); }
+        { const char* e = getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
+        { const char* e = getenv("F3DS_MERGE_COMPACT_MIN"); merge_compact_min = e ? (size_t)atol(e) : (size_t)-1; }
+        relabel_lds_cap = num("F3DS_RELABEL_LDS_CAP", -1);
+    }
+};
+thread_local Switches g_sw;
+
 }  // namespace
 
 struct f3ds_ctx {
@@ -239,7 +260,6 @@ thread_local int g_batch_frames = 1;      // frames of the batch call this threa
 // batch calls inside f3ds_segment_batch right now, per device: a call whose merge dispatch shares the chip with other calls takes the 4-wave merge kernel (choose_merge_kind)
 std::atomic<int> g_batch_calls[16];
 struct BatchCallCount { int d; explicit BatchCallCount(int dev) : d(dev & 15) { g_batch_calls[d].fetch_add(1, std::memory_order_relaxed); } ~BatchCallCount() { g_batch_calls[d].fetch_sub(1, std::memory_order_relaxed); } };
-thread_local unsigned long long g_norm_t0 = ~0ull, g_norm_t1 = 0ull;      // device-clock window of the call's d_normals launch
 size_t grid_cap_for_batch(int frames) {
     static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
     if (!target) return 2048;
@@ -292,7 +312,7 @@ struct Batch {
 thread_local double g_t_wait = 0, g_t_launch = 0;
 // F3DS_TRACE_ERR=1: say which stage refused a frame (development aid)
 static int trace_err(int code, const char* where, const f3ds_ctx* c) {
-    if (code && getenv("F3DS_TRACE_ERR"))
+    if (code && g_sw.trace_err)
         fprintf(stderr, "f3ds: error %d after %s (V %u, seeds %u, edges %u, chain overflow %d, capacity flag %d)\n", code, where, c->V, c->S0, c->h_dc->n_edges,
                 c->h_dc->r_overflow, c->h_dc->ev_overflow);
     return code;
@@ -432,7 +452,7 @@ int seg_sort(f3ds_ctx* c, int sort_bits, int idxbits) {      // idxbits >= 0: (c
     int rc = radix_sort(c, k0, v0, k1, v1, n, sort_bits, &c->ks, &c->vs, ks);
     if (rc) return rc;
     const uint64_t invalid = 1ull << (3 * c->h_dc->depth);
-    if (getenv("F3DS_SPLIT_VOXEL_ACCUM")) {      // development: round 2's chain (d_point_gather reads the rank array)
+    if (g_sw.split_voxel_accum) {      // development: round 2's chain (d_point_gather reads the rank array)
         rec<d_heads>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, n, invalid, flags, ks);
         if ((rc = scan_u32(c, flags, incl, n))) return rc;
         rec<d_segstart>(c, grid_for(n, 256), 0u, (const uint64_t*)c->ks, (const uint32_t*)flags, (const uint32_t*)incl, n, invalid, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid, ks);
@@ -454,7 +474,7 @@ int seg_voxels(f3ds_ctx* c) {
     ENSURE(c->vkey, uint32_t, (size_t)V * 3, vkey); ENSURE(c->vcount, uint32_t, V, vcount); ENSURE(c->vf, float, (size_t)V * 12, vf);
     ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hcap, hkeys); ENSURE(c->hvals, uint32_t, hcap, hvals);
     rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hcap * 8);
-    if (getenv("F3DS_SPLIT_VOXEL_ACCUM")) {      // development: round 2's two kernels (a sorted copy of the frame in between)
+    if (g_sw.split_voxel_accum) {      // development: round 2's two kernels (a sorted copy of the frame in between)
         P16* spts; ENSURE(c->spts, P16, n, spts);
         rec<d_point_gather>(c, grid_wide(n, 256), 0u, c->d_pts, (const uint32_t*)c->vs, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->incl.p, n, (const DevCounters*)c->d_dc, spts, (int*)c->pt_voxel.p);
         rec<d_voxel_accum>(c, grid_wide(V, 256), 0u, (const P16*)spts, (const uint64_t*)c->ks, c->idxbits < 0 ? 0 : c->idxbits, (const uint32_t*)c->seg_start.p, (const DevCounters*)c->d_dc, c->fa,
@@ -483,8 +503,8 @@ int seg_normals(f3ds_ctx* c) {
 #endif
     const uint32_t share = budget ? std::max(2u, budget / (uint32_t)g_batch_frames) : nt;
     // 256 threads per tile for the calls of a batch pipeline (their workgroups fit beside the 4-wave merge loops of the other calls), 384 otherwise (kernels.inc)
-    const int nthr_env = getenv("F3DS_NORMALS_THREADS") ? atoi(getenv("F3DS_NORMALS_THREADS")) : 0;
-    const uint32_t holes = (uint32_t)(getenv("F3DS_SWEEP_TILE_HOLES") ? atoi(getenv("F3DS_SWEEP_TILE_HOLES")) : 0);
+    const int nthr_env = g_sw.normals_threads;
+    const uint32_t holes = g_sw.tile_holes;
     if (nthr_env ? nthr_env == 256 : g_batch_frames >= 16)
         rec<d_normals_t<256>>(c, std::min(nt, share), 0u, (float*)c->vf.p, (const int*)c->nbr.p, (const DevCounters*)c->d_dc, tn1, tord, tslots, holes);
     else
@@ -581,7 +601,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
     a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.chg = chg; a.wl = wl; a.wl2 = wl2;
     a.thr = g_inc_shift >= 32 ? 0xFFFFFFFFu : (g_inc_shift < 0 ? 0u : V >> g_inc_shift);
-    if (getenv("F3DS_SWEEP_TILES") && !atoi(getenv("F3DS_SWEEP_TILES"))) a.tile_n1 = nullptr;      // development: F3DS_SWEEP_TILES=0 keeps the sweeps on their global-gather path (A/B, tests)
+    if (!g_sw.sweep_tiles) a.tile_n1 = nullptr;      // development: F3DS_SWEEP_TILES=0 keeps the sweeps on their global-gather path (A/B, tests)
     else a.tile_n1 = (const uint32_t*)c->tile_n1.p;
     a.tile_ord = (const uint32_t*)c->tile_ord.p; a.tile_slots = (const uint32_t*)c->tile_slots.p;
     for (uint32_t t = 0; t < c->res.sweeps; ++t) {
@@ -655,7 +675,7 @@ bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {  
     xl->stage2_off = 0u; xl->spec = 0;
     if (nw >= 4) {      // staging area of an epoch's speculative second merge, switched off by F3DS_MERGE_SPEC=0
         xl->stage2_off = (uint32_t)total; total += (uint64_t)MC_SP_ROWS * 52u + (uint64_t)MC_SP_TL * 8u + 64u;
-        xl->spec = (getenv("F3DS_MERGE_SPEC") && !atoi(getenv("F3DS_MERGE_SPEC"))) ? 0 : 1;
+        xl->spec = g_sw.merge_spec ? 1 : 0;
     }
     xl->stage_off = (uint32_t)stage_off; xl->lds_bytes = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
     xl->keys_in_lds = res;
@@ -673,12 +693,12 @@ inline int mk_res(int kind) { return 2 - (kind - MK_CW) % 3; }
 // A frame whose arrays do not fit, or with more than 65534 seeds, takes d_merge.  Development switches:
 // F3DS_MERGE_NW=2|4|8, F3DS_MERGE_COMPACT_MIN=<frames> (2 waves from that many frames), F3DS_FORCE_GLOBAL_MERGE.
 int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
-    if (force_global || getenv("F3DS_FORCE_GLOBAL_MERGE")) return MK_GLOBAL;
-    const char* e_nw = getenv("F3DS_MERGE_NW"); const char* e_keys = getenv("F3DS_MERGE_KEYS"); const char* e_min = getenv("F3DS_MERGE_COMPACT_MIN");
-    const size_t compact_min = e_min ? (size_t)atol(e_min) : (size_t)-1;
+    if (force_global || g_sw.force_global_merge) return MK_GLOBAL;
+    const bool e_keys = g_sw.merge_keys >= 0;
+    const size_t compact_min = g_sw.merge_compact_min;
     const bool shared = fr.size() >= 16 && g_batch_calls[fr[0]->device & 15].load(std::memory_order_relaxed) >= 2;
-    const int nw = e_nw ? (atoi(e_nw) == 2 ? 2 : (atoi(e_nw) == 4 ? 4 : 8)) : (fr.size() >= compact_min ? 2 : (shared ? 4 : 8));
-    const int first = e_keys ? (!strcmp(e_keys, "lds") ? 2 : (!strcmp(e_keys, "global") ? 1 : 0)) : (nw >= 4 ? 2 : 1);
+    const int nw = g_sw.merge_nw ? g_sw.merge_nw : (fr.size() >= compact_min ? 2 : (shared ? 4 : 8));
+    const int first = e_keys ? g_sw.merge_keys : (nw >= 4 ? 2 : 1);
     for (int res = first; res >= (e_keys ? first : 0); --res) {
         bool ok = true;
         for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, res, &t)) { ok = false; break; } }
@@ -751,12 +771,14 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
 }
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
+#ifdef F3DS_WHATIF      // make WHATIF=1 only: the stand-in changes the labels, so the default library does not contain it
     if (const char* e = getenv("F3DS_FAKE_MERGE")) {      // experiment, timing only: see d_fake_merge
         unsigned us = 30000, waves = 1; sscanf(e, "%u,%u", &us, &waves);
         const char* l = getenv("F3DS_FAKE_MERGE_LDS");
         rec<d_fake_merge>(c, 1u, l ? (uint32_t)atoi(l) * 1024u : c->mlds.lds_bytes, c->mdev, (uint32_t)us, (uint32_t)waves);
         return F3DS_OK;
     }
+#endif
     switch (c->merge_kind) {
         case MK_CW + 0: rec<d_merge_cw_t<2, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         case MK_CW + 1: rec<d_merge_cw_t<2, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
@@ -843,7 +865,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     stage_mark(b, 6);
     for (size_t i = 0; i < b.fr.size(); ++i) b.fr[i]->user_labels = (labels_on_device && labels_of) ? labels_of[index_of[i]] : nullptr;
     {
-        const uint32_t cap = getenv("F3DS_RELABEL_LDS_CAP") ? (uint32_t)atol(getenv("F3DS_RELABEL_LDS_CAP")) : RL_LDS_CAP;      // (tests: 0 forces the two-kernel form)
+        const uint32_t cap = g_sw.relabel_lds_cap >= 0 ? (uint32_t)g_sw.relabel_lds_cap : RL_LDS_CAP;      // (tests: 0 forces the two-kernel form)
         bool fits = true;
         for (f3ds_ctx* c : b.fr) if (c->S0 + 1u > cap) fits = false;
         for (f3ds_ctx* c : b.fr) c->relabel_lds = fits;
@@ -866,7 +888,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
             if (c->h_dc->ev_overflow == 2 && c->pool_mult < 64u) { c->pool_mult *= 4u; again = true; }
         }
         if (again) {
-            if (getenv("F3DS_TRACE_ERR")) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with more history / leaf-pool room\n", b.fr.size());
+            if (g_sw.trace_err) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with more history / leaf-pool room\n", b.fr.size());
             for (f3ds_ctx* c : b.fr) {
                 c->h_dc->error = 0; c->h_dc->ev_overflow = 0;
                 HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->ev_overflow, 0, sizeof(int), b.st));
@@ -880,7 +902,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         bool again = false;
         for (f3ds_ctx* c : b.fr) if (c->h_dc->error == F3DS_ERR_UNSUPPORTED) again = true;
         if (again) {
-            if (getenv("F3DS_TRACE_ERR")) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with the global-memory kernel\n", b.fr.size());
+            if (g_sw.trace_err) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with the global-memory kernel\n", b.fr.size());
             for (f3ds_ctx* c : b.fr) { c->h_dc->error = 0; HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); }
             return run_cluster(b, prm, labels_of, index_of, labels_on_device, true);
         }
@@ -979,12 +1001,13 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     for (int i = 0; i < nctx; ++i) if (!ctxs[i] || (!points[i] && counts[i]) || counts[i] > 0x7fffffffull || ctxs[i]->device != ctxs[0]->device) return F3DS_ERR_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     g_t_wait = 0; g_t_launch = 0;
+    g_sw.read();
     HIPCHECK(hipSetDevice(ctxs[0]->device));
     BatchCallCount in_flight(ctxs[0]->device);
     Batch b;
     b.owner = ctxs[0]; b.st = ctxs[0]->stream;
     BatchStreamLease lease;
-    if (nctx > 1 && ctxs[0]->stream == ctxs[0]->own_stream && !getenv("F3DS_NO_STREAM_POOL")) { hipStream_t ps = lease.acquire(ctxs[0]->device); if (ps) b.st = ps; }
+    if (nctx > 1 && ctxs[0]->stream == ctxs[0]->own_stream && !g_sw.no_stream_pool) { hipStream_t ps = lease.acquire(ctxs[0]->device); if (ps) b.st = ps; }
     g_grid_cap = grid_cap_for_batch(nctx); g_batch_frames = nctx;
     std::vector<int> index_of;
     const int max_depth = (int)(1.8f * prm->seed_res / prm->voxel_res);      // [PCL-recall] SupervoxelClustering::extract
@@ -1032,7 +1055,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     uint32_t maxn = 1;
     for (f3ds_ctx* c : b.fr) if (c->n > maxn) maxn = c->n;
     int idxbits = bits_for((uint64_t)maxn - 1u);
-    if (3 * maxd + 1 + idxbits > 64 || getenv("F3DS_SORT_PAIRS")) idxbits = -1;
+    if (3 * maxd + 1 + idxbits > 64 || g_sw.sort_pairs) idxbits = -1;
     if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_sort(c, 3 * maxd + 1, idxbits); })) || (rc = flush_sync(b))) return rc;
     for (f3ds_ctx* c : b.fr) { c->V = c->h_dc->n_voxels; c->res.n_voxels = c->V; }
     if ((rc = drop_dead([](f3ds_ctx* c) { return c->V == 0; }))) return rc;
@@ -1044,8 +1067,6 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = for_frames(b, seg_seed_grid)) || (rc = flush(b))) return rc;
     stage_mark(b, 2);
     if ((rc = flush_sync(b))) return rc;
-    g_norm_t0 = ~0ull; g_norm_t1 = 0ull;
-    for (f3ds_ctx* c : b.fr) { if (c->h_dc->t_norm0 < g_norm_t0) g_norm_t0 = c->h_dc->t_norm0; if (c->h_dc->t_norm1 > g_norm_t1) g_norm_t1 = c->h_dc->t_norm1; }
     int maxsd = 0;
     for (f3ds_ctx* c : b.fr) { if (c->h_dc->error) return c->h_dc->error; if (c->h_dc->sdepth > maxsd) maxsd = c->h_dc->sdepth; }
     if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_seed_cells(c, 3 * maxsd, maxsd); })) || (rc = flush_sync(b))) return rc;
@@ -1063,7 +1084,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
         bool again = false;
         for (f3ds_ctx* c : b.fr) if (c->h_dc->ev_overflow == 3 && c->edge_mult < (1u << 14)) { c->edge_mult *= 4u; again = true; }
         if (!again) break;
-        if (getenv("F3DS_TRACE_ERR")) fprintf(stderr, "f3ds: adjacency pass of %zu frames runs again with more list room\n", b.fr.size());
+        if (g_sw.trace_err) fprintf(stderr, "f3ds: adjacency pass of %zu frames runs again with more list room\n", b.fr.size());
         for (f3ds_ctx* c : b.fr) {
             c->h_dc->error = 0; c->h_dc->ev_overflow = 0;
             HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->ev_overflow, 0, sizeof(int), b.st));
@@ -1086,13 +1107,11 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     float stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // device time of each stage of the whole batch (HIP events on the batch's stream)
     for (int k = 0; k < 7; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[k], b.owner->ev[k + 1]) == hipSuccess) stage[k] = ms; }
-    // the d_normals launch (inside stage 1): its execution window on the device clock -- first workgroup started to last workgroup ended, over the frames of the
-    // call: what a kernel trace calls its duration.  (The HIP-event pair around the dispatch reads 10-15 ms more with six calls in flight: the time the dispatch
-    // sits at the head of its queue before a compute unit has 72 KB of LDS and six wave slots free for its first workgroup.)
-    if (g_norm_t1 > g_norm_t0) stage[7] = (float)((double)(g_norm_t1 - g_norm_t0) * 1e-5);
-    else if (!b.fr.empty()) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[9], b.owner->ev[10]) == hipSuccess) stage[7] = ms; }
+    // the d_normals launch (inside stage 1): a HIP event pair around that one dispatch on the call's stream (the time it waits at the head of its queue
+    // for a compute unit with room for its first workgroup + its execution)
+    if (!b.fr.empty()) { float ms = 0; if (hipEventElapsedTime(&ms, b.owner->ev[9], b.owner->ev[10]) == hipSuccess) stage[7] = ms; }
     const float ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (getenv("F3DS_HOST_PROF")) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic; stages %.0f %.0f %.0f %.0f %.0f %.0f %.0f ms; %llu scratch allocations so far\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch, stage[0], stage[1], stage[2], stage[3], stage[4], stage[5], stage[6], g_scratch_allocs.load());
+    if (g_sw.host_prof) fprintf(stderr, "batch of %d: %.1f ms total, %.1f waiting for the GPU, %.1f packing + launching, %.1f recording / host logic; stages %.0f %.0f %.0f %.0f %.0f %.0f %.0f ms; %llu scratch allocations so far\n", nctx, ms, g_t_wait, g_t_launch, ms - g_t_wait - g_t_launch, stage[0], stage[1], stage[2], stage[3], stage[4], stage[5], stage[6], g_scratch_allocs.load());
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
         for (int k = 0; k < 8; ++k) c->res.ms_stage[k] = stage[k];
@@ -1106,6 +1125,7 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     if (!c || !prm) return F3DS_ERR_ARG;
     if (!c->have_frame) return F3DS_ERR_LOGIC;
     const auto t0 = std::chrono::steady_clock::now();
+    g_sw.read();
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
     c->cmds.clear(); c->blob.clear(); c->pend.clear();
@@ -1200,6 +1220,7 @@ extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, fl
 extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
     if (!c || num_itr < 0) return F3DS_ERR_ARG;
     if (!c->have_frame) return F3DS_ERR_LOGIC;
+    g_sw.read();
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
     c->cmds.clear(); c->blob.clear(); c->pend.clear();

@@ -12,6 +12,7 @@
 
 #include "../../include/f3ds.h"
 #include "f3ds_glasbey.h"
+#include "f3ds_build_stamp.h"
 #include "f3ds_math.h"
 
 extern "C" {
@@ -37,6 +38,14 @@ void f3ds_default_params(f3ds_params* p) {
 }
 
 int f3ds_version(void) { return F3DS_VERSION; }
+// "f3ds <version> src:<stamp>[ +whatif]": the stamp is the hash of the sources this library was built from (csrc/Makefile)
+const char* f3ds_version_string(void) {
+#ifdef F3DS_WHATIF
+    return "f3ds 1.1.0 src:" F3DS_BUILD_STAMP " +whatif";
+#else
+    return "f3ds 1.1.0 src:" F3DS_BUILD_STAMP;
+#endif
+}
 
 const char* f3ds_strerror(int code) {
     switch (code) {

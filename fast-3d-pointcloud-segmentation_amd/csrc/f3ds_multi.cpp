@@ -18,7 +18,12 @@
 //     that already carries a librccl (PyTorch bundles one) keeps using that copy.  With one GPU no RCCL call is made at all;
 //   * an RCCL error inside the group aborts the communicators (ncclCommAbort) instead of closing a group with an unmatched send --
 //     the driver then refuses further batches (F3DS_ERR_HIP) rather than hang;
-//   * the calling thread's current HIP device is left as it was.
+//   * the calling thread's current HIP device is left as it was;
+//   * LOGICAL DEVICES (F3DS_MULTI_LOGICAL=1, tests on 1-GPU boxes): the `devices` array may then name one GPU several times (or more
+//     entries than GPUs are visible; NULL = logical device d on GPU d mod visible).  Every entry is a device of its own to the driver --
+//     its own worker thread, contexts, label blocks, stream, its own block/base/off arithmetic -- so everything of the G > 1 path runs
+//     except the wire: RCCL refuses a communicator with duplicate GPUs, so the peers' blocks reach devices[0]'s gathered block with
+//     hipMemcpyAsync (device to device) where a real node uses ncclSend / ncclRecv.  Never a production mode: no speed-up comes of it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -118,8 +123,11 @@ struct f3ds_multi {
     std::deque<Job*> exch_queue;           // batches whose compute is complete on every device, in submission order
     std::thread exchanger;
     std::unique_ptr<Job> ring[SLOTS];
-    int next_ticket = 0, last_slot = -1;
-    bool stop = false, broken = false;     // broken: the communicators were aborted after an RCCL error
+    int next_ticket = 0;
+    std::atomic<int> last_slot{-1};        // written by the exchange thread, read by f3ds_multi_gathered_labels without the lock
+    bool stop = false;
+    std::atomic<bool> broken{false};       // the communicators were aborted after an RCCL error (set by the exchange thread)
+    bool logical = false;                  // F3DS_MULTI_LOGICAL: entries of `devices` may share a GPU; the exchange is a device-to-device copy
 };
 
 namespace {
@@ -177,7 +185,16 @@ int exchange(f3ds_multi* m, Job& j, std::string* err) {
     const int G = (int)m->dev.size();
     PerDevice& root = m->dev[0];
     const int s = j.slot;
-    if (G > 1) {
+    if (G > 1 && m->logical) {
+        // logical devices: same arithmetic (block / base per device), the peers' blocks copied device to device on the root's stream
+        for (int d = 1; d < G; ++d) {
+            if (!j.block[(size_t)d]) continue;
+            if (hipSetDevice(root.device) != hipSuccess ||
+                hipMemcpyAsync(root.labels[s] + j.base[(size_t)d], m->dev[(size_t)d].labels[s], j.block[(size_t)d] * sizeof(uint32_t), hipMemcpyDeviceToDevice, root.stream) != hipSuccess) {
+                *err = "hipMemcpyAsync(logical peer block)"; return F3DS_ERR_HIP;
+            }
+        }
+    } else if (G > 1) {
         ncclResult_t r = g_rccl.GroupStart();
         bool posted = false;
         for (int d = 1; d < G && r == ncclSuccess; ++d) {
@@ -193,7 +210,7 @@ int exchange(f3ds_multi* m, Job& j, std::string* err) {
             // a send without its receive (or the reverse) is pending inside the open group: closing the group could wait for ever.
             // Abort every communicator; this driver does no further exchange.
             for (size_t d = 0; d < m->comm.size(); ++d) if (m->comm[d]) { (void)hipSetDevice(m->dev[d].device); (void)g_rccl.CommAbort(m->comm[d]); m->comm[d] = nullptr; }
-            m->broken = true;
+            m->broken.store(true);
             *err = std::string("RCCL label exchange (communicators aborted): ") + g_rccl.GetErrorString(r);
             return F3DS_ERR_HIP;
         }
@@ -237,7 +254,7 @@ void exchanger_loop(f3ds_multi* m) {
         {
             std::lock_guard<std::mutex> lk(m->mu);
             if (rc && !j->rc) { j->rc = rc; j->err = err; }
-            j->done = true; m->last_slot = j->slot;
+            j->done = true; m->last_slot.store(j->slot);
         }
         m->cv_done.notify_all();
     }
@@ -277,21 +294,23 @@ int f3ds_multi_create(const int* devices, int n_devices, int max_frames_per_devi
     *out = nullptr;
     const int visible = f3ds_device_count();
     if (visible <= 0) return F3DS_ERR_NO_DEVICE;
-    if (n_devices <= 0 || n_devices > visible || max_frames_per_device <= 0) return F3DS_ERR_ARG;
+    const bool logical = getenv("F3DS_MULTI_LOGICAL") != nullptr;      // tests: several logical devices on one GPU (see the head of this file)
+    if (n_devices <= 0 || (n_devices > visible && !logical) || n_devices > 64 || max_frames_per_device <= 0) return F3DS_ERR_ARG;
     DeviceGuard guard;
     f3ds_multi* m = new f3ds_multi;
     m->max_frames_per_device = max_frames_per_device;
+    m->logical = logical;
     m->dev.resize((size_t)n_devices);
     for (int d = 0; d < n_devices; ++d) {
-        const int id = devices ? devices[d] : d;
+        const int id = devices ? devices[d] : (logical ? d % visible : d);
         if (id < 0 || id >= visible) { f3ds_multi_destroy(m); return F3DS_ERR_ARG; }
-        for (int e = 0; e < d; ++e) if (m->dev[(size_t)e].device == id) { f3ds_multi_destroy(m); return F3DS_ERR_ARG; }
+        if (!logical) for (int e = 0; e < d; ++e) if (m->dev[(size_t)e].device == id) { f3ds_multi_destroy(m); return F3DS_ERR_ARG; }
         m->dev[(size_t)d].device = id;
         if (hipSetDevice(id) != hipSuccess || hipStreamCreateWithFlags(&m->dev[(size_t)d].stream, hipStreamNonBlocking) != hipSuccess) { f3ds_multi_destroy(m); return F3DS_ERR_HIP; }
     }
     // development / single-GPU test boxes: F3DS_MULTI_FORCE_RCCL=1 builds the communicator with one device too and sends the
     // label block through RCCL to itself, so that the library loading and the grouped send/recv are exercised on one GPU
-    if (n_devices > 1 || getenv("F3DS_MULTI_FORCE_RCCL")) {
+    if (!logical && (n_devices > 1 || getenv("F3DS_MULTI_FORCE_RCCL"))) {
         if (!g_rccl.load()) { g_multi_error = "librccl not found (F3DS_RCCL_LIB, librccl.so.1, /opt/rocm/lib)"; f3ds_multi_destroy(m); return F3DS_ERR_UNSUPPORTED; }
         std::vector<int> ids;
         for (const PerDevice& p : m->dev) ids.push_back(p.device);
@@ -336,7 +355,7 @@ int f3ds_multi_submit(f3ds_multi* m, const void* const* points, const size_t* co
     if (n_frames > G * m->max_frames_per_device) return F3DS_ERR_CAPACITY;
     for (int i = 0; i < n_frames; ++i) if ((!points[i] && counts[i]) || counts[i] > 0x7fffffffull) return F3DS_ERR_ARG;
     std::unique_lock<std::mutex> lk(m->mu);
-    if (m->broken) { g_multi_error = "the RCCL communicators of this driver were aborted after an error"; return F3DS_ERR_HIP; }
+    if (m->broken.load()) { g_multi_error = "the RCCL communicators of this driver were aborted after an error"; return F3DS_ERR_HIP; }
     const int t = m->next_ticket, slot = t % SLOTS;
     if (m->ring[slot] && !m->ring[slot]->collected) return F3DS_ERR_BUSY;      // two batches in flight: collect the older one first (its status lives in this slot)
     std::unique_ptr<Job> j(new Job);
@@ -386,8 +405,18 @@ int f3ds_multi_segment(f3ds_multi* m, const void* const* points, const size_t* c
 // their running offsets inside [dev 0 | dev 1 | ...]) -- for callers that keep the labels on the GPU; valid until the
 // batch after the next one is submitted (two slots)
 const uint32_t* f3ds_multi_gathered_labels(const f3ds_multi* m) {
-    if (!m || m->dev.empty() || m->last_slot < 0) return nullptr;
-    return m->dev[0].labels[m->last_slot];
+    if (!m || m->dev.empty()) return nullptr;
+    const int s = m->last_slot.load();
+    return s < 0 ? nullptr : m->dev[0].labels[s];
+}
+// the same for a given batch: NULL unless that batch has been gathered and its slot not handed to a later batch yet (the block is
+// overwritten once the batch submitted two calls after it starts computing on devices[0])
+const uint32_t* f3ds_multi_gathered_labels_of(f3ds_multi* m, int ticket) {
+    if (!m || m->dev.empty() || ticket < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(m->mu);
+    const Job* j = m->ring[ticket % SLOTS].get();
+    if (!j || j->ticket != ticket || !j->done || j->rc) return nullptr;
+    return m->dev[0].labels[j->slot];
 }
 
 }  // extern "C"

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define F3DS_VERSION 100
+#define F3DS_VERSION 110
 
 /* label written for points that belong to no region (non-finite input point, or a voxel no
  * supervoxel ever claimed).  The reference never emits such points at all
@@ -91,14 +91,18 @@ typedef struct f3ds_result {
     float ms_stage[8];            /* device time per stage (HIP events): 0 voxelise,
                                      1 neighbours+normals, 2 seeds, 3 sweeps, 4 supervoxel
                                      summaries+edges, 5 merge, 6 labels; 7 = the voxel-normal
-                                     kernel's launch alone (part of stage 1): first workgroup
-                                     started .. last one ended, on the device's clock   */
+                                     kernel's launch alone (part of stage 1): HIP event pair
+                                     around that dispatch on the call's stream          */
 } f3ds_result;
 
 typedef struct f3ds_ctx f3ds_ctx;
 
 void f3ds_default_params(f3ds_params* p);
 int f3ds_version(void);
+/* "f3ds 1.1.0 src:<16 hex digits>": the digits are the SHA-256 prefix of the sources the library was built from
+ * (csrc/Makefile writes it at build time); tests and bench.py compare it with the sources on disk so that a stale
+ * prebuilt libf3ds.so fails loudly.  A library built with the timing experiments compiled in ends in " +whatif". */
+const char* f3ds_version_string(void);
 const char* f3ds_strerror(int code);
 const char* f3ds_last_hip_error(void);
 
@@ -261,7 +265,9 @@ int f3ds_stream_pending(f3ds_stream* s);
  * CMakeLists.txt:5).  Frame i runs on devices[i mod n_devices], one host thread per GPU; the per-point labels of all
  * frames then go to devices[0] in ONE grouped RCCL send/recv exchange (the ragged form of ncclGather, each peer over its
  * own xGMI link) and from there to the caller's host buffers.  librccl is loaded at run time; with one device no RCCL
- * call is made (unless F3DS_MULTI_FORCE_RCCL is set: development).  Results per frame are those of f3ds_segment. */
+ * call is made (unless F3DS_MULTI_FORCE_RCCL is set: development).  Results per frame are those of f3ds_segment.
+ * F3DS_MULTI_LOGICAL=1 (tests on 1-GPU boxes): `devices` may name one GPU several times -- every entry is a device of its own
+ * to the driver (worker thread, contexts, label blocks), the exchange a device-to-device copy in place of ncclSend / ncclRecv. */
 typedef struct f3ds_multi f3ds_multi;
 /* devices == NULL: devices 0..n_devices-1.  max_frames_per_device bounds one f3ds_multi_segment call. */
 int f3ds_multi_create(const int* devices, int n_devices, int max_frames_per_device, f3ds_multi** out);
@@ -273,8 +279,9 @@ int f3ds_multi_device_of_frame(const f3ds_multi* m, int frame);
  * results may be NULL.  F3DS_ERR_CAPACITY when n_frames > n_devices * max_frames_per_device. */
 int f3ds_multi_segment(f3ds_multi* m, const void* const* points, const size_t* counts, int n_frames, const f3ds_params* params,
                        uint32_t* const* point_labels, f3ds_result* results);
-/* Pipelined form: f3ds_multi_submit queues a batch (same arguments; the arrays are copied, the point and label buffers must stay
- * valid until the batch is collected) and returns a ticket; the GPUs compute batch k+1 while batch k's labels are gathered on
+/* Pipelined form: f3ds_multi_submit queues a batch (same arguments; the pointer arrays are copied; the point buffers, the label
+ * buffers AND the `results` array are written / read asynchronously by the driver's threads and must stay valid until the batch
+ * is collected) and returns a ticket; the GPUs compute batch k+1 while batch k's labels are gathered on
  * devices[0] and copied to the host buffers.  At most two batches are in flight: F3DS_ERR_BUSY when the batch submitted two
  * calls ago has not been collected yet.  f3ds_multi_collect waits for a batch and returns its status (once per ticket).
  * f3ds_multi_segment == submit + collect. */
@@ -287,6 +294,9 @@ int f3ds_multi_reserve(f3ds_multi* m, size_t max_points_per_frame);
 /* the gathered label block on devices[0] of the batch gathered last (device pointer): device d's frames, in frame order, start
  * at the sum of the point counts of the devices before d; valid until the batch after the next one is submitted */
 const uint32_t* f3ds_multi_gathered_labels(const f3ds_multi* m);
+/* the gathered block of a given batch (ticket of f3ds_multi_submit): NULL unless that batch has been gathered without error and its
+ * slot has not been handed to a later batch */
+const uint32_t* f3ds_multi_gathered_labels_of(f3ds_multi* m, int ticket);
 const char* f3ds_multi_last_error(void);
 
 /* ---- host-side helpers either side of the path (no GPU needed) -------------------------- */

@@ -17,7 +17,7 @@
 //                                                  src/color_utilities.cpp:117-160,190-319
 //     rgb2lab calls cv::cvtColor(COLOR_RGB2Lab) (OpenCV 4, absent): restated analytically, PARITY
 //     UNPINNED; lab_ciede00 and rgb_eucl are pinned by the reference's own known-answer tables
-//     (src/color_utilities.cpp:324-349,354-460 -> tests/golden/ciede2000_kat.json).
+//     (src/color_utilities.cpp:324-349,354-460 -> tests/golden/reference_kat.json).
 //
 // Style: literal.  std::set / std::map / std::list follow the containers the reference and PCL
 // use so that iteration order, tie order and float summation order are the reference's.
@@ -240,6 +240,22 @@ void rgb2lab(const float rgb[3], float lab[3]) {
     lab[0] = Y > 0.008856f ? 116.0f * fy - 16.0f : 903.3f * Y;
     lab[1] = 500.0f * (fx - fy);
     lab[2] = 200.0f * (fy - fz);
+}
+
+// OpenCV-distance estimate (tests/test_pins.py): OpenCV 4's float RGB -> Lab goes through a trilinearly interpolated LUT by default and
+// deviates from the analytic formula above by up to ~1e-1 Lab units ([OpenCV-recall]).  With f3ds_oracle_set_lab_perturb(amp)
+// every Lab triple the distances see is moved by a deterministic field of amplitude amp -- a hash of the colour's bits, so the same colour
+// always moves the same way, as a LUT error would -- and the test reports how far labels and weights move.  amp = 0 (default): nothing.
+static float g_lab_perturb = 0.0f;
+void lab_perturb(const float rgb[3], float lab[3]) {
+    if (g_lab_perturb == 0.0f) return;
+    uint32_t w[3]; std::memcpy(w, rgb, 12);
+    uint64_t h = ((uint64_t)w[0] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)w[1] * 0xC2B2AE3D27D4EB4Full) ^ ((uint64_t)w[2] * 0x165667B19E3779F9ull);
+    for (int k = 0; k < 3; ++k) {
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33;
+        const float u = (float)((h >> 11) & 0xFFFFF) / (float)0xFFFFF;      // [0, 1]
+        lab[k] += g_lab_perturb * (2.0f * u - 1.0f);
+    }
 }
 
 // src/color_utilities.cpp:190-294, kL = kC = kH = 1
@@ -764,6 +780,7 @@ struct Clusterer {
         if (prm.color_metric == F3DS_LAB_CIEDE00) {
             float lab1[3], lab2[3];
             rgb2lab(rgb1, lab1); rgb2lab(rgb2, lab2);
+            lab_perturb(rgb1, lab1); lab_perturb(rgb2, lab2);      // (a no-op unless a test asks for the OpenCV-distance estimate)
             delta_c = lab_ciede00(lab1, lab2);
             delta_c /= LAB_RANGE;
         } else {
@@ -1113,6 +1130,7 @@ int f3ds_oracle_refine(f3ds_oracle* op, int num_itr, uint32_t* voxel_sv_label, f
 float f3ds_oracle_ciede00(const float* lab1, const float* lab2) { return lab_ciede00(lab1, lab2); }
 float f3ds_oracle_rgb_eucl(const float* a, const float* b) { return rgb_eucl(a, b); }
 void f3ds_oracle_rgb2lab(const float* rgb, float* lab) { rgb2lab(rgb, lab); }
+void f3ds_oracle_set_lab_perturb(float amp) { g_lab_perturb = amp; }      // process-wide; tests reset it to 0
 void f3ds_oracle_normal(const float* xyz, size_t n, const float* view_point, float* normal4) {
     float curv;
     std::vector<XYZ> pts(n);

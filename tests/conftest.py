@@ -21,9 +21,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_stamp_checked = False
+
+
 def pkg():
-    """The product package (its directory name has hyphens, so import it by string)."""
-    return importlib.import_module("fast-3d-pointcloud-segmentation_amd")
+    """The product package (its directory name has hyphens, so import it by string).  On first use the loaded libf3ds.so is checked
+    against the sources on disk (build stamp, f3ds_version_string): a stale prebuilt library fails every test that touches it."""
+    global _stamp_checked
+    P = importlib.import_module("fast-3d-pointcloud-segmentation_amd")
+    if not _stamp_checked:
+        P.check_library_is_current()
+        _stamp_checked = True
+    return P
 
 
 def _make(directory, target=None):
@@ -133,24 +142,21 @@ def P():
 @pytest.fixture(scope="session")
 def oracle():
     p = os.path.join(ROOT, "oracle", "libf3ds_oracle.so")
-    if not os.path.exists(p):
-        _make("oracle")
+    _make("oracle")           # (a no-op when the library is newer than its sources)
     return CpuChecker(p, "f3ds_oracle")
 
 
 @pytest.fixture(scope="session")
 def oracle_libm():
     p = os.path.join(ROOT, "oracle", "libf3ds_oracle_libm.so")
-    if not os.path.exists(p):
-        _make("oracle")
+    _make("oracle")
     return CpuChecker(p, "f3ds_oracle")
 
 
 @pytest.fixture(scope="session")
 def emul():
     p = os.path.join(ROOT, "tests", "emul", "libf3ds_emul.so")
-    if not os.path.exists(p):
-        _make("tests/emul")
+    _make("tests/emul")
     return CpuChecker(p, "f3ds_emul")
 
 

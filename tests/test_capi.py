@@ -18,7 +18,8 @@ def test_every_declared_symbol_is_exported(P):
     assert len(names) >= 16
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.f3ds_version() == 100
+    assert lib.f3ds_version() == 110
+    assert lib.f3ds_version_string().decode().startswith("f3ds 1.1.0 src:")
 
 
 def test_struct_layout_matches_header(P):

@@ -1,5 +1,6 @@
 """GPU parity proper: libf3ds (HIP, through the C-ABI) against the CPU oracle and the committed
 golden file, bit for bit, on every intermediate array.  Sizes: the oracle finishes in seconds."""
+import ctypes
 import hashlib
 import json
 import os
@@ -983,3 +984,67 @@ def test_lds_tiled_sweeps_equal_the_global_gather_sweeps(P, env):
         assert got[n]["labels"] == GOLD[n]["labels_sha256"], (n, env)
         for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
             assert got[n][w] == GOLD[n]["sha256"][w], (n, w, env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 3])
+def test_multi_gpu_driver_logical_devices_run_the_g_gt_1_path(P, oracle, monkeypatch, G):
+    """The G > 1 logic of f3ds_multi_* on a 1-GPU box (F3DS_MULTI_LOGICAL: `devices` names GPU 0 G times).  Every logical device has its own
+    worker thread, contexts and label blocks; frame i runs on logical device i mod G; the per-device block / base / off arithmetic, the
+    exchange thread with several devices and the two-slot pipeline all run -- only the wire differs (device-to-device copies where a real node
+    uses ncclSend / ncclRecv: RCCL refuses duplicate GPUs).  Five ragged frames (one empty), pipelined submit / collect, labels == single
+    calls, and the gathered block on devices[0] laid out [dev 0 | dev 1 | ...] in frame order."""
+    monkeypatch.setenv("F3DS_MULTI_LOGICAL", "1")
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.1)
+    batches = [[P.synth_frame(0, 700 + 10 * b + i, 120 + 24 * i, 90 + 10 * ((i + b) % 3), 30) for i in range(5)] for b in range(3)]
+    batches[1][2] = np.zeros((0, 4), np.float32)                   # a device whose share holds an empty frame
+    batches[2] = batches[2][:G - 1]                                # fewer frames than devices: the last device idles
+    want = [[oracle.segment(f, prm)[1] for f in fr] for fr in batches]
+    mg = P.MultiGpu(devices=[0] * G, max_frames_per_device=3)
+    assert mg.devices() == G and [mg.device_of_frame(i) for i in range(5)] == [i % G for i in range(5)]
+    t0 = mg.submit(batches[0], prm); t1 = mg.submit(batches[1], prm)
+    with pytest.raises(P.F3dsError) as e:
+        mg.submit(batches[2], prm)
+    assert e.value.code == P.ERR_BUSY
+    got0, res0 = mg.collect(t0)
+    # the gathered block of batch 0 on devices[0]: device d's frames in frame order at the running offset of the devices before d
+    hip = ctypes.CDLL("libamdhip64.so")
+    blk = mg.lib.f3ds_multi_gathered_labels_of(mg.handle, t0)
+    assert blk
+    order = [i for d in range(G) for i in range(d, 5, G)]
+    total = sum(len(batches[0][i]) for i in order)
+    host = np.empty(total, np.uint32)
+    assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(blk), ctypes.c_size_t(total * 4), 2) == 0      # hipMemcpyDeviceToHost
+    assert np.array_equal(host, np.concatenate([want[0][i] for i in order]))
+    t2 = mg.submit(batches[2], prm)
+    got1, _ = mg.collect(t1); got2, _ = mg.collect(t2)
+    assert mg.lib.f3ds_multi_gathered_labels_of(mg.handle, t0) is None      # its slot now belongs to batch 2
+    for b, got in enumerate((got0, got1, got2)):
+        assert len(got) == len(want[b]) and all(np.array_equal(g, w) for g, w in zip(got, want[b])), b
+    assert [r.n_points for r in res0] == [len(f) for f in batches[0]]
+    with pytest.raises(P.F3dsError) as e:
+        mg.segment(batches[0] * 2, prm)                            # 10 frames > G x 3 only when G = 2 or 3
+    assert e.value.code == P.ERR_CAPACITY
+    mg.close()
+    monkeypatch.delenv("F3DS_MULTI_LOGICAL")
+    with pytest.raises(P.F3dsError):
+        P.MultiGpu(devices=[0, 0])                                 # duplicates stay an error outside the test mode
+
+
+@pytest.mark.gpu
+def test_bench_distributed_bookkeeping_with_one_forced_rank(tmp_path):
+    """bench.py's N > 1 branch -- process group, per-step RCCL gather of the label block, barrier, max-over-ranks timing -- with one rank
+    (F3DS_BENCH_FORCE_DIST=1) on small frames: the line is well-formed and says what it ran.  (A scaling curve needs a node: not claimed.)"""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, F3DS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--groups", "2", "--width", "160", "--height", "120",
+                        "--host-io-steps", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode in (0, 1), r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "Mpoints/s" and line["scaling"] == "weak"
+    assert "RCCL gather" in line["config"]["label_gather"] and line["config"]["frames_timed"] == 128
+    assert line["roofline"]["kernel"].startswith("k_batched<d_merge") and line["library"].startswith("f3ds 1.1.0 src:")
+    # 160x120 frames are not BASELINE's workload: the line carries no `value`, the rate sits under what_if_value
+    assert line["value"] is None and "not the BASELINE workload" in line["invalid"] and line["what_if_value"] > 0
