@@ -312,8 +312,8 @@ def main():
         # call group's context after the timed region (above) -- what its LAST call ran -- and the most frequent answer names the kernel)
         layouts = merge_layouts
         lay = max(layouts, key=layouts.get) if layouts else (8, 2)
-        merge_name = "k_batched<d_merge_cw_t<%d,%d>>" % lay if lay[0] else "k_batched<d_merge>"
-        KERNELS = {5: (merge_name, "merge", "d_merge_cw_t"), 7: ("k_batched<d_normals_t<%d>>" % (256 if nbatch >= 16 else 384), "neighbours+normals", "d_normals_t")}      # (256 threads per tile in calls of >= 16 frames)
+        merge_name = "k_batched<d_merge_il_t<%d,%d>>" % lay if lay[0] else "k_batched<d_merge>"
+        KERNELS = {5: (merge_name, "merge", "d_merge_il_t"), 7: ("k_batched<d_normals_t<%d>>" % (256 if nbatch >= 16 else 384), "neighbours+normals", "d_normals_t")}      # (256 threads per tile in calls of >= 16 frames)
         # the merge loop is the first kernel by total time in the kernel trace of this command (profiles/r4_kernel_stats.csv), and the one kernel whose
         # event pair brackets exactly one dispatch; the voxel-normal launch's pair is reported beside it (dominant_by), it includes that dispatch's wait for a unit
         dom = 5
@@ -329,7 +329,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             pk = pm["kernels"]
-            traffic = int((pk.get(KERNELS[dom][2]) or pk[KERNELS[dom][2].replace("_t", "")])["hbm_bytes_per_frame"] * frames_per_launch)
+            traffic = int((pk.get(KERNELS[dom][2]) or pk.get("d_merge_cw_t") or pk[KERNELS[dom][2].replace("_t", "")])["hbm_bytes_per_frame"] * frames_per_launch)
             path_traffic = int(pm["whole_path_hbm_bytes_per_frame"])          # upper bound (every read request taken as 128 bytes)
             path_traffic_min = int(pm["whole_path_hbm_bytes_per_frame_min"])  # lower bound (64-byte requests in the kernels that gather)
         except Exception:

@@ -9,7 +9,7 @@
 //                d_centroid, d_centroid_mark  
 //   4 summaries  d_sv_fill (payload rows + ordered leaf sums), d_edges, radix sort, d_edge_init,
 //                d_edge_deltas, d_lambda / d_cdf_*, d_edge_weights
-//   5 merge      d_merge_cw_t<2, 4 or 8 waves, LDS residency> (one persistent workgroup per frame), d_merge (global memory)
+//   5 merge      d_inc_build, d_merge_il_t<4 or 8 waves, per-edge arrays in LDS or L2> (one persistent workgroup per frame), d_merge (global memory)
 //   6 labels     d_relabel (union-find relabel in LDS + per-point label write; d_region_ids + d_point_labels beyond 12 k supervoxels)
 // Every frame RECORDS its kernel calls; flush() zips the records of a batch into one dispatch per kernel (grid.y = frame).
 //
@@ -101,7 +101,7 @@ const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e 
 // where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
 struct Switches {
     bool split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
-    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0; size_t merge_compact_min = (size_t)-1; long relabel_lds_cap = -1;
+    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0; long relabel_lds_cap = -1;
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
@@ -109,13 +109,15 @@ struct Switches {
         force_global_merge = on("F3DS_FORCE_GLOBAL_MERGE"); no_stream_pool = on("F3DS_NO_STREAM_POOL"); sort_pairs = on("F3DS_SORT_PAIRS");
         host_prof = on("F3DS_HOST_PROF"); trace_err = on("F3DS_TRACE_ERR");
         normals_threads = (int)num("F3DS_NORMALS_THREADS", 0); tile_holes = (uint32_t)num("F3DS_SWEEP_TILE_HOLES", 0);
-        { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 2 ? 2 : (v == 4 ? 4 : (v ? 8 : 0)); }
+        { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 4 ? 4 : (v ? 8 : 0); }
         { const char* e = getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
-        { const char* e = getenv("F3DS_MERGE_COMPACT_MIN"); merge_compact_min = e ? (size_t)atol(e) : (size_t)-1; }
         relabel_lds_cap = num("F3DS_RELABEL_LDS_CAP", -1);
     }
 };
 thread_local Switches g_sw;
+// where the per-edge arrays of a 4-wave merge loop live when the call shares the device with other batch calls: 0 = global memory (52 KB of LDS per
+// workgroup: two fit a unit, and a voxel-normal workgroup beside them), 2 = LDS (up to 140 KB).  F3DS_MERGE_SHARED_RES=0|2 (A/B runs), read once.
+const int g_merge_shared_res = [] { const char* e = getenv("F3DS_MERGE_SHARED_RES"); return e && atoi(e) == 2 ? 2 : (e && atoi(e) == 0 ? 0 : 0); }();
 
 }  // namespace
 
@@ -167,7 +169,7 @@ struct f3ds_ctx {
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
     Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
-    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
+    Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, ilist, istart, ilen, icap, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
 
@@ -664,45 +666,34 @@ int seg_edge_sort(f3ds_ctx* c, int sort_bits) {
     rec<d_edge_init>(c, grid_for(E, 256), 0u, (const uint64_t*)c->eks, E, S0, ea0, eb0);
     return F3DS_OK;
 }
-// d_merge_cw_t<NW, keys in LDS>: LDS layout for a frame with E adjacencies
-bool merge_cw_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {      // res: 2 = endpoints + keys in LDS, 1 = endpoints, 0 = neither
+// d_merge_il_t<NW, RES>: LDS a frame with E adjacencies needs (merge_il_offsets, f3ds_kernels.inc) and whether the kernel can take it
+bool merge_il_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {      // res: 2 = endpoints + keys in LDS, 0 = both in global memory
     memset(xl, 0, sizeof *xl);
-    const uint32_t T = (uint32_t)nw * 64u, CH = T < 256u ? T : (nw == 4 ? 128u : 256u);
-    xl->Ecap = (E + 4u * T - 1u) / (4u * T) * (4u * T); if (!xl->Ecap) xl->Ecap = 4u * T;      // every thread scans whole 4-edge groups: no bounds tests
-    const uint64_t fixed = (uint64_t)xl->Ecap * 4u * (uint32_t)res + MC_TL_CAP * 16u + (2u * T + 1u) * 4u;
-    const uint64_t stage_off = (fixed + 15u) & ~(uint64_t)15u;
-    uint64_t total = stage_off + 2u * CH * 52u + 64u;      // (+ 64: the fold loops read up to 16 rows ahead)
-    xl->stage2_off = 0u; xl->spec = 0;
-    if (nw >= 4) {      // staging area of an epoch's speculative second merge, switched off by F3DS_MERGE_SPEC=0
-        xl->stage2_off = (uint32_t)total; total += (uint64_t)MC_SP_ROWS * 52u + (uint64_t)MC_SP_TL * 8u + 64u;
-        xl->spec = g_sw.merge_spec ? 1 : 0;
-    }
-    xl->stage_off = (uint32_t)stage_off; xl->lds_bytes = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
-    xl->keys_in_lds = res;
-    return total <= 160u * 1024u - 2048u && S0 <= 65534u;      // (2 KB: the kernel's static LDS)
+    if ((uint64_t)E * (res == 2 ? 10u : 2u) > (1u << 22)) return false;              // (far beyond what fits: keep the 32-bit offsets below honest)
+    const MergeIlLayout L = merge_il_offsets(E, nw, res);
+    xl->Ecap = L.Ecap; xl->NGcap = L.NGcap; xl->lds_bytes = L.total; xl->keys_in_lds = res;
+    xl->spec = g_sw.merge_spec ? 1 : 0;      // (the speculative second merge of an epoch; F3DS_MERGE_SPEC=0 switches it off)
+    return L.total <= 160u * 1024u - 2560u && S0 <= 65534u;      // (2.5 KB: the kernel's static LDS)
 }
-// merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_CW + (8 waves ? 3 : 0) + (2 - res)
-enum MergeKind { MK_GLOBAL = 0, MK_CW = 1 };
-inline int mk_waves(int kind) { return (kind - MK_CW) >= 6 ? 4 : ((kind - MK_CW) >= 3 ? 8 : 2); }
-inline int mk_res(int kind) { return 2 - (kind - MK_CW) % 3; }
-// Which merge kernel a batch runs (one dispatch for all its frames): 8 waves per frame and everything that fits in LDS -- the shortest loop, what a lone frame or
-// a lone call wants.  A call of 16 frames or more that shares the device with other batch calls takes the 4-wave layout instead: its loop is ~20 % longer, but a
+// merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_IL + (8 waves ? 0 : 2) + (res == 2 ? 0 : 1)
+enum MergeKind { MK_GLOBAL = 0, MK_IL = 1 };
+inline int mk_waves(int kind) { return (kind - MK_IL) >= 2 ? 4 : 8; }
+inline int mk_res(int kind) { return (kind - MK_IL) % 2 ? 0 : 2; }
+// Which merge kernel a batch runs (one dispatch for all its frames): 8 waves per frame with keys and endpoints in LDS -- the shortest loop, what a lone frame or
+// a lone call wants.  A call of 16 frames or more that shares the device with other batch calls takes the 4-wave layout instead: its loop is longer, but a
 // workgroup holds one wave slot and 250 registers per SIMD instead of two and 500, and the other calls' wide kernels run on the units the merge loops sit on
-// (+2 ... +11 % on the bench's six calls in flight over six alternating runs on three boxes; two waves: longer still, no gain).  Results are identical whatever
-// runs.  F3DS_MERGE_KEYS=lds|global|none (order keys and endpoints in LDS | endpoints only | neither) and the 2-wave layout stay selectable.
-// A frame whose arrays do not fit, or with more than 65534 seeds, takes d_merge.  Development switches:
-// F3DS_MERGE_NW=2|4|8, F3DS_MERGE_COMPACT_MIN=<frames> (2 waves from that many frames), F3DS_FORCE_GLOBAL_MERGE.
+// (DESIGN.md 4i).  Results are identical whatever runs.  F3DS_MERGE_KEYS=lds|global says where the per-edge arrays live, F3DS_MERGE_NW=4|8 the width.
+// A frame whose arrays fit neither way, or with more than 65534 seeds, takes d_merge.  F3DS_FORCE_GLOBAL_MERGE forces it (tests).
 int choose_merge_kind(const std::vector<f3ds_ctx*>& fr, bool force_global) {
     if (force_global || g_sw.force_global_merge) return MK_GLOBAL;
     const bool e_keys = g_sw.merge_keys >= 0;
-    const size_t compact_min = g_sw.merge_compact_min;
     const bool shared = fr.size() >= 16 && g_batch_calls[fr[0]->device & 15].load(std::memory_order_relaxed) >= 2;
-    const int nw = g_sw.merge_nw ? g_sw.merge_nw : (fr.size() >= compact_min ? 2 : (shared ? 4 : 8));
-    const int first = e_keys ? g_sw.merge_keys : (nw >= 4 ? 2 : 1);
-    for (int res = first; res >= (e_keys ? first : 0); --res) {
+    const int nw = g_sw.merge_nw ? (g_sw.merge_nw == 8 ? 8 : 4) : (shared ? 4 : 8);
+    const int first = e_keys ? (g_sw.merge_keys == 2 ? 2 : 0) : (shared ? g_merge_shared_res : 2);
+    for (int res = first; res >= (e_keys ? first : 0); res -= 2) {
         bool ok = true;
-        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_cw_layout(c->E, c->S0, nw, res, &t)) { ok = false; break; } }
-        if (ok) return MK_CW + (nw == 8 ? 3 : (nw == 4 ? 6 : 0)) + (2 - res);
+        for (f3ds_ctx* c : fr) { MergeLds t; if (!merge_il_layout(c->E, c->S0, nw, res, &t)) { ok = false; break; } }
+        if (ok) return MK_IL + (nw == 8 ? 0 : 2) + (res == 2 ? 0 : 1);
     }
     return MK_GLOBAL;
 }
@@ -737,11 +728,15 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     rec_copy(c, m.ea, c->ea0.p, (size_t)E * 4);
     rec_copy(c, m.eb, c->eb0.p, (size_t)E * 4);
     MergeLds xl;
-    merge_cw_layout(E, S0, use_lds ? mk_waves(kind) : 8, use_lds ? mk_res(kind) : 0, &xl);
+    merge_il_layout(E, S0, use_lds ? mk_waves(kind) : 8, use_lds ? mk_res(kind) : 0, &xl);
     uint32_t logS = 1; while ((1u << logS) < S0 + 2u) ++logS;
     xl.pool_cap = (S0 + 1u) * (4u * logS + 8u) * c->pool_mult;
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
     ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
+    // incident-edge lists of the regions (d_inc_build): the initial lists take 2 E entries, a merge whose touched list outgrows a's segment takes a fresh one
+    { const uint64_t cap = 2ull * E + 32ull * E * c->pool_mult + 1024u; xl.ilist_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }
+    ENSURE(c->ilist, uint32_t, xl.ilist_cap, xl.ilist); ENSURE(c->istart, uint32_t, S0 + 1, xl.istart); ENSURE(c->ilen, uint32_t, S0 + 1, xl.ilen); ENSURE(c->icap, uint32_t, S0 + 1, xl.icap);
+    if (use_lds) rec<d_inc_build>(c, 1u, 0u, E, S0, (const uint32_t*)m.ea, (const uint32_t*)m.eb, xl.istart, xl.ilen, xl.icap, xl.ilist);
     xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);
     c->merge_in_lds = use_lds; c->merge_kind = kind;
     rec<d_region_reset>(c, grid_for(S0 + 1, 256), 0u, S0, (const uint32_t*)c->hcount.p, m.rhead, m.rtail, m.lnext, m.parent, m.markA, m.markB, xl.pool, xl.rstart, xl.rnleaf, xl.rcap, (const uint32_t*)c->loff.p);
@@ -780,15 +775,10 @@ int seg_merge(f3ds_ctx* c) {
     }
 #endif
     switch (c->merge_kind) {
-        case MK_CW + 0: rec<d_merge_cw_t<2, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 1: rec<d_merge_cw_t<2, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 2: rec<d_merge_cw_t<2, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 3: rec<d_merge_cw_t<8, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 4: rec<d_merge_cw_t<8, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 5: rec<d_merge_cw_t<8, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 6: rec<d_merge_cw_t<4, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 7: rec<d_merge_cw_t<4, 1>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
-        case MK_CW + 8: rec<d_merge_cw_t<4, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_IL + 0: rec<d_merge_il_t<8, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_IL + 1: rec<d_merge_il_t<8, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_IL + 2: rec<d_merge_il_t<4, 2>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
+        case MK_IL + 3: rec<d_merge_il_t<4, 0>>(c, 1u, c->mlds.lds_bytes, c->mdev, c->mlds); break;
         default: rec<d_merge>(c, 1u, 0u, c->mdev);
     }
     return F3DS_OK;

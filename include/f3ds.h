@@ -173,9 +173,9 @@ enum {
     F3DS_DBG_SV_REGION = 19,      /* S u32 surviving label each supervoxel ended in             */
     F3DS_DBG_TILE_LIST_LEN = 21,  /* ceil(V / 128) u32: length of each 128-voxel tile's one-ring list (the LDS tiles of the normals and
                                      the sweeps); 0xFFFFFFFF = the tile did not fit the tables and took the global-memory path.  Diagnostics */
-    F3DS_DBG_MERGE_LAYOUT = 20    /* 2 u32: which merge kernel the last cluster stage ran -- waves per frame (2, 4, 8; 0 = d_merge,
-                                     everything in global memory) and what it kept in LDS (2 = order keys + endpoints, 1 = endpoints,
-                                     0 = neither).  Diagnostics (bench.py names the kernel it timed): results do not depend on it */
+    F3DS_DBG_MERGE_LAYOUT = 20    /* 2 u32: which merge kernel the last cluster stage ran -- waves per frame (4, 8; 0 = d_merge,
+                                     everything in global memory) and where it kept the per-edge arrays (2 = order keys + endpoints in
+                                     LDS, 0 = in global memory).  Diagnostics (bench.py names the kernel it timed): results do not depend on it */
 };
 int f3ds_get_debug(f3ds_ctx* ctx, int what, void* dst, size_t cap_bytes, size_t* bytes_out);
 

@@ -10,7 +10,7 @@ prm = P.launch_params(voxel_res=0.008, seed_res=0.08)
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = [P.synth_frame(0, 1000 + i, 1000, 1000, 30) for i in range(min(nb, 8))]
 ctxs = [P.Context(0) for _ in range(nb)]
-VARIANTS = [dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("8", "2") for k in ("lds", "global", "none")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")]
+VARIANTS = [dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("8", "4") for k in ("lds", "global")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")]
 for v in VARIANTS:
     for k in ("F3DS_FORCE_GLOBAL_MERGE", "F3DS_MERGE_NW", "F3DS_MERGE_KEYS"):
         os.environ.pop(k, None)
