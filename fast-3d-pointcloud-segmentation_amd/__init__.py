@@ -98,7 +98,8 @@ def load_library(path=None):
     vp, sz, u32p = ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)
     lib.f3ds_default_params.argtypes = [ctypes.POINTER(Params)]; lib.f3ds_default_params.restype = None
     lib.f3ds_version.restype = ctypes.c_int
-    lib.f3ds_version_string.restype = ctypes.c_char_p
+    if hasattr(lib, "f3ds_version_string"):      # (F3DS_LIB may point at an older build during A/B runs)
+        lib.f3ds_version_string.restype = ctypes.c_char_p
     lib.f3ds_strerror.argtypes = [ctypes.c_int]; lib.f3ds_strerror.restype = ctypes.c_char_p
     lib.f3ds_last_hip_error.restype = ctypes.c_char_p
     lib.f3ds_device_count.restype = ctypes.c_int
@@ -136,7 +137,8 @@ def load_library(path=None):
     lib.f3ds_multi_collect.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_collect.restype = ctypes.c_int
     lib.f3ds_multi_reserve.argtypes = [vp, sz]; lib.f3ds_multi_reserve.restype = ctypes.c_int
     lib.f3ds_multi_gathered_labels.argtypes = [vp]; lib.f3ds_multi_gathered_labels.restype = vp
-    lib.f3ds_multi_gathered_labels_of.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_gathered_labels_of.restype = vp
+    if hasattr(lib, "f3ds_multi_gathered_labels_of"):
+        lib.f3ds_multi_gathered_labels_of.argtypes = [vp, ctypes.c_int]; lib.f3ds_multi_gathered_labels_of.restype = vp
     lib.f3ds_multi_last_error.restype = ctypes.c_char_p
     lib.f3ds_stream_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_stream_create.restype = ctypes.c_int
     lib.f3ds_stream_destroy.argtypes = [vp]; lib.f3ds_stream_destroy.restype = None
