@@ -141,3 +141,58 @@ def test_multi_gpu_driver_argument_checks_need_no_gpu(P):
     assert lib.f3ds_multi_collect(None, 0) == P.ERR_ARG and lib.f3ds_multi_reserve(None, 1000) == P.ERR_ARG
     lib.f3ds_multi_destroy(None)
     assert isinstance(lib.f3ds_multi_last_error(), bytes)
+
+
+def test_cpp_clustering_adapter(P, tmp_path):
+    """include/f3ds_clustering.hpp -- the header-only C++ mirror of class Clustering (clustering.h:116-211) and of the
+    pcl::SupervoxelClustering call sequence over the C-ABI -- compiles against libf3ds, throws the reference's exceptions before an
+    initial state is set, and (on a GPU box) reproduces the labels of a plain f3ds_segment call."""
+    src = tmp_path / "adapter.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "f3ds_clustering.hpp"
+int main() {
+    f3ds::Clustering c;                                                    // defaults of clustering.cpp:533-539
+    if (c.get_delta_c() != f3ds::LAB_CIEDE00 || c.get_delta_g() != f3ds::NORMALS_DIFF || c.get_merging() != f3ds::ADAPTIVE_LAMBDA) return 10;
+    if (c.get_lambda() != 0.5f || c.get_bins_num() != 500) return 11;
+    try { c.set_lambda(0.3f); return 12; } catch (const std::logic_error&) {}            // :574-582
+    try { c.set_bins_num(10); return 13; } catch (const std::logic_error&) {}            // :589-597
+    c.set_merging(f3ds::MANUAL_LAMBDA);
+    try { c.set_lambda(1.5f); return 14; } catch (const std::invalid_argument&) {}
+    c.set_lambda(0.25f); if (c.get_lambda() != 0.25f) return 15;
+    c.set_merging(f3ds::EQUALIZATION);
+    try { c.set_bins_num(-1); return 16; } catch (const std::invalid_argument&) {}
+    try { c.cluster(0.2f); return 17; } catch (const std::logic_error&) {}               // :670-673
+    if (f3ds_device_count() < 1) { std::puts("no device: surface only"); return 0; }
+    const uint32_t W = 160, H = 120;
+    std::vector<f3ds::PointXYZRGBA> pts((size_t)W * H);
+    if (f3ds_synth_frame(0, 7, W, H, 30, pts.data())) return 20;
+    f3ds::SupervoxelClustering super(0.02f, 0.2f);
+    super.setInputCloud(pts.data(), pts.size());
+    f3ds::Supervoxels sv = super.extract();
+    f3ds::Clustering seg(f3ds::LAB_CIEDE00, f3ds::CONVEX_NORMALS_DIFF, f3ds::ADAPTIVE_LAMBDA);
+    seg.set_initialstate(super);
+    seg.cluster(0.2f);
+    // the same frame through the plain C call
+    f3ds_ctx* ctx; if (f3ds_create(0, &ctx)) return 21;
+    f3ds_params p; f3ds_default_params(&p); p.voxel_res = 0.02f; p.seed_res = 0.2f; p.geom_metric = F3DS_CONVEX_NORMALS_DIFF; p.threshold = 0.2f;
+    std::vector<uint32_t> want(pts.size()); f3ds_result r;
+    if (f3ds_segment(ctx, pts.data(), pts.size(), 0, &p, want.data(), 0, &r)) return 22;
+    if (seg.get_point_labels() != want) return 23;
+    if (seg.result().n_regions != r.n_regions || sv.label.size() != r.n_supervoxels || seg.get_lambda() != r.lambda) return 24;
+    f3ds::LabeledCloud lc = seg.get_labeled_cloud(); f3ds::ColoredCloud cc = seg.get_colored_cloud();
+    if (lc.label.empty() || lc.label.size() != cc.rgba.size() || cc.rgba[0] != f3ds_label_color(lc.label[0])) return 25;
+    if (super.getSupervoxelAdjacency().size() != r.n_edges) return 26;
+    f3ds_destroy(ctx);
+    std::puts("adapter ok");
+    return 0;
+}
+''')
+    pkg_dir = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd")
+    exe = tmp_path / "adapter"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-L", pkg_dir, "-lf3ds", "-Wl,-rpath," + pkg_dir], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert ("adapter ok" in r.stdout) == (P.device_count() > 0)
