@@ -65,8 +65,15 @@ __device__ __forceinline__ void unpack_call(const ArgPack<T, Ts...>& p, Done... 
 // on a CU: the long-running, latency-bound kernels (the merge loop, the voxel normals) otherwise fence whole CUs off for the wide ones.
 template <class K, class = void> struct waves_per_simd { static constexpr int v = 1; };
 template <class K> struct waves_per_simd<K, std::void_t<decltype(K::WAVES_PER_SIMD)>> { static constexpr int v = K::WAVES_PER_SIMD; };
+// The single-workgroup-per-frame kernels (serial scans, the seed-grid growth, the sweep's device-side decisions) sit on every call's critical path and do little:
+// with other calls' wide kernels on the chip their waves are raised in priority (F3DS_EXP_NO_LATENCY_PRIO: A/B)
+template <class K, class = void> struct is_latency_kernel { static constexpr bool v = false; };
+template <class K> struct is_latency_kernel<K, std::void_t<decltype(K::LATENCY_KERNEL)>> { static constexpr bool v = K::LATENCY_KERNEL; };
 template <class K, class Pack>
 __global__ __launch_bounds__(K::BLOCK, waves_per_simd<K>::v) void k_batched(const Pack* frames) {
+#ifndef F3DS_EXP_NO_LATENCY_PRIO
+    if constexpr (is_latency_kernel<K>::v) __builtin_amdgcn_s_setprio(3);
+#endif
     const Pack p = frames[f3ds_frame()];      // XCD-aware (frame, block) mapping: f3ds_kernels.inc
     unpack_call<K>(p);
 }
