@@ -142,6 +142,7 @@ struct f3ds_ctx {
     std::vector<Cmd> cmds;
     std::vector<unsigned char> blob;
     std::vector<uintptr_t> pend;       // device addresses the recorded calls refer to (pointer arguments; every aligned word of struct arguments)
+    MultiOp ops = {}; uint32_t ops_grid = 0;      // fills / copies recorded in a row and not yet turned into a d_multi_op call (flush_ops)
     // pinned + device staging for the packed arguments of a batch (owned by the batch's first context)
     unsigned char* h_args[2] = {nullptr, nullptr}; unsigned char* d_args[2] = {nullptr, nullptr}; size_t args_cap = 0;      // two arenas, used in turn: a flush never waits for the stream
     hipEvent_t ev_args[2] = {nullptr, nullptr}; bool args_used[2] = {false, false}; int args_flip = 0;
@@ -189,6 +190,10 @@ namespace {
 bool referenced_by_pending_calls(const f3ds_ctx* c, const Buf& b) {
     const uintptr_t lo = (uintptr_t)b.p, hi = lo + b.cap;
     for (const uintptr_t w : c->pend) if (w >= lo && w < hi) return true;
+    for (uint32_t k = 0; k < c->ops.n; ++k) {      // (fills / copies recorded and not yet merged into a call)
+        const uintptr_t d = (uintptr_t)c->ops.dst[k], sp = (uintptr_t)c->ops.src[k];
+        if ((d >= lo && d < hi) || (sp >= lo && sp < hi)) return true;
+    }
     return false;
 }
 template <class A> inline void note_arg(f3ds_ctx* c, const A& a) {
@@ -221,7 +226,7 @@ int ensure(f3ds_ctx* c, Buf& b, size_t count, T** out) {
     // fit (the caller is about to overwrite the buffer anyway).  The device-wide mark sizes such a regrow; buffers that are merely
     // below the mark are brought up to it by pregrow_scratch() at the start of a segment call, when no buffer holds frame state.
     if (b.cap < bytes) {
-        if (b.p && !c->cmds.empty() && referenced_by_pending_calls(c, b)) {
+        if (b.p && (!c->cmds.empty() || c->ops.n) && referenced_by_pending_calls(c, b)) {
             fprintf(stderr, "f3ds: internal error: regrowing a buffer that a recorded kernel call refers to\n");
             return F3DS_ERR_LOGIC;
         }
@@ -289,8 +294,17 @@ inline uint32_t pow2_ge(size_t x) { uint32_t p = 1; while (p < x) p <<= 1; retur
 int bits_for(uint64_t max_value) { int b = 0; while (b < 64 && (max_value >> b)) ++b; return b; }
 
 // record one kernel call of frame `c` (nothing is launched here)
+template <class K, class... As> void rec(f3ds_ctx* c, uint32_t gx, uint32_t lds, As... as);
+// the fills / copies recorded since the last other call become one d_multi_op call (every frame of a batch records the same sequence, so the same grouping)
+inline void flush_ops(f3ds_ctx* c) {
+    if (!c->ops.n) return;
+    const MultiOp m = c->ops; const uint32_t g = c->ops_grid;
+    c->ops.n = 0; c->ops_grid = 0;
+    rec<d_multi_op>(c, g, 0u, m);
+}
 template <class K, class... As>
 void rec(f3ds_ctx* c, uint32_t gx, uint32_t lds, As... as) {
+    if constexpr (!std::is_same<K, d_multi_op>::value) flush_ops(c);
     using Pack = pack_of<K>;
     static_assert(std::is_trivially_copyable<Pack>::value, "kernel arguments must be plain data");
     Pack p;
@@ -302,14 +316,17 @@ void rec(f3ds_ctx* c, uint32_t gx, uint32_t lds, As... as) {
     memcpy(c->blob.data() + cmd.off, &p, sizeof(Pack));
     c->cmds.push_back(cmd);
 }
-inline void rec_fill(f3ds_ctx* c, void* p, uint32_t value, size_t bytes) {
+inline void rec_op(f3ds_ctx* c, void* dst, const void* src, uint32_t value, size_t bytes) {
     const uint32_t words = (uint32_t)((bytes + 3) / 4);
-    rec<d_fill_u32>(c, grid_for(words, 256), 0u, (uint32_t*)p, value, words);
+    if (c->ops.n == (uint32_t)MULTI_OPS) flush_ops(c);
+    MultiOp& m = c->ops;
+    if (m.n == 0) memset(&m, 0, sizeof m);
+    m.dst[m.n] = (uint32_t*)dst; m.src[m.n] = (const uint32_t*)src; m.val[m.n] = value; m.words[m.n] = words; m.n++;
+    const uint32_t g = grid_for(words, 256);
+    if (g > c->ops_grid) c->ops_grid = g;
 }
-inline void rec_copy(f3ds_ctx* c, void* dst, const void* src, size_t bytes) {
-    const uint32_t words = (uint32_t)((bytes + 3) / 4);
-    rec<d_copy_u32>(c, grid_for(words, 256), 0u, (uint32_t*)dst, (const uint32_t*)src, words);
-}
+inline void rec_fill(f3ds_ctx* c, void* p, uint32_t value, size_t bytes) { rec_op(c, p, nullptr, value, bytes); }
+inline void rec_copy(f3ds_ctx* c, void* dst, const void* src, size_t bytes) { rec_op(c, dst, src, 0u, bytes); }
 
 // a batch: the frames that are still being processed together, one stream, one argument arena
 struct Batch {
@@ -330,6 +347,7 @@ static inline double now_ms() { return std::chrono::duration<double, std::milli>
 // zip the recorded calls of all live frames into batched dispatches
 int flush(Batch& b, hipEvent_t before_launch = nullptr) {      // before_launch: recorded after the argument upload, right before the first dispatch
     if (b.fr.empty()) return F3DS_OK;
+    for (f3ds_ctx* c : b.fr) flush_ops(c);
     const size_t ncmd = b.fr[0]->cmds.size();
     for (f3ds_ctx* c : b.fr) if (c->cmds.size() != ncmd) return F3DS_ERR_UNSUPPORTED;   // frames must take the same path
     if (ncmd == 0) return F3DS_OK;
@@ -373,7 +391,7 @@ int flush(Batch& b, hipEvent_t before_launch = nullptr) {      // before_launch:
         HIPCHECK(b.fr[0]->cmds[j].fn(gx, nf, lds, b.st, d_args + off[j]));
     }
     HIPCHECK(hipEventRecord(o->ev_args[fl], b.st)); o->args_used[fl] = true;
-    for (f3ds_ctx* c : b.fr) { c->cmds.clear(); c->blob.clear(); c->pend.clear(); }
+    for (f3ds_ctx* c : b.fr) { c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0; }
     g_t_launch += now_ms() - tl0;
     return F3DS_OK;
 }
@@ -594,7 +612,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     rec_fill(c, owner0, 0u, (size_t)V * 4);
     rec_fill(c, ghost_head, 0u, (size_t)V * 4);
     rec_fill(c, ghost_next, 0u, (size_t)(S0 + 1) * 4);
-    rec<d_fill_f32>(c, grid_for(V, 256), 0u, dist0, V, F3DS_FLT_MAX);
+    { const float fmax = F3DS_FLT_MAX; uint32_t bits; memcpy(&bits, &fmax, 4); rec_fill(c, dist0, bits, (size_t)V * 4); }
     if (sb.reseed) {
         rec<d_reseed_own>(c, grid_for(S0, 256), 0u, sb.seeds, S0, owner0);
         rec<d_reseed_init>(c, grid_for(S0 + 1, 256), 0u, sb.seeds, S0, (const uint32_t*)owner0, ghost_vox, ghost_active, ghost_done, hlo, hhi, hcount, tl, tcnt);
@@ -1012,7 +1030,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     stage_mark(b, 0);
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
-        c->cmds.clear(); c->blob.clear(); c->pend.clear();
+        c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
         c->have_frame = false; c->live = true; c->rc = 0; c->refined_itr = -1;
         { const int prc = pregrow_scratch(c); if (prc) return prc; }
         c->prm = *prm; c->n = (uint32_t)counts[i]; c->V = c->C = c->S0 = c->E = 0;
@@ -1125,7 +1143,7 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     g_sw.read();
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
-    c->cmds.clear(); c->blob.clear(); c->pend.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
     c->h_dc->error = 0;
     HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), c->stream));
     stage_mark(b, 4);
@@ -1220,7 +1238,7 @@ extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
     g_sw.read();
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
-    c->cmds.clear(); c->blob.clear(); c->pend.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
     c->refined_itr = -1;
     const uint32_t V = c->V, S0 = c->S0;
     float *r_vf, *r_hc; uint32_t *r_owner, *r_hcount, *L; int *r_gvox, *seed; unsigned char* r_gact;
@@ -1434,7 +1452,7 @@ int eval_truth(f3ds_ctx* c, const uint32_t* truth_point_labels) {
     HIPCHECK(hipMemcpyAsync(tp, truth_point_labels, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(hipMemsetAsync(tsum, 0, (size_t)V * 12, c->stream));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
-    c->cmds.clear(); c->blob.clear(); c->pend.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
     rec<d_truth_accum>(c, grid_for(n, 256), 0u, n, (const int*)c->pt_voxel.p, (const uint32_t*)tp, (const uint32_t*)lut, tsum);
     rec<d_truth_color>(c, grid_for(V, 256), 0u, V, (const uint32_t*)tsum, (const uint32_t*)c->vcount.p, tcol);
     int rc = flush_sync(b);
@@ -1462,7 +1480,7 @@ int eval_scores(f3ds_ctx* c, const uint32_t* d_root, const uint32_t* d_incl, uin
     HIPCHECK(hipMemsetAsync(tab, 0, (size_t)K * M * 4, c->stream));
     HIPCHECK(hipMemsetAsync(ssz, 0, (size_t)K * 4, c->stream));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
-    c->cmds.clear(); c->blob.clear(); c->pend.clear();
+    c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
     rec<d_contingency>(c, grid_for(V, 256), 0u, V, M, (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
     rec<d_contingency_ghost>(c, grid_for(c->S0, 256), 0u, c->S0, M, (const int*)c->ghost_vox.p, (const unsigned char*)c->ghost_active.p,
                              (const uint32_t*)c->owner0.p, d_root, d_incl, (const uint32_t*)c->tlab.p, tab, ssz);
