@@ -108,7 +108,7 @@ const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e 
 // where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
 struct Switches {
     bool split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
-    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0; long relabel_lds_cap = -1;
+    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32; long relabel_lds_cap = -1;
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
@@ -119,6 +119,7 @@ struct Switches {
         { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 4 ? 4 : (v ? 8 : 0); }
         { const char* e = getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
         relabel_lds_cap = num("F3DS_RELABEL_LDS_CAP", -1);
+        { const long v = num("F3DS_ILIST_SLACK", 32); ilist_slack = v >= 1 && v <= 32 ? (uint32_t)v : 32u; }      // tests: a short incident-list pool (the merge stage then reruns with a larger one)
     }
 };
 thread_local Switches g_sw;
@@ -759,7 +760,7 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
     ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
     // incident-edge lists of the regions (d_inc_build): the initial lists take 2 E entries, a merge whose touched list outgrows a's segment takes a fresh one
-    { const uint64_t cap = 2ull * E + 32ull * E * c->pool_mult + 1024u; xl.ilist_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }
+    { const uint64_t cap = 2ull * E + (uint64_t)g_sw.ilist_slack * E * c->pool_mult + (g_sw.ilist_slack < 32u ? 16u : 1024u); xl.ilist_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }
     ENSURE(c->ilist, uint32_t, xl.ilist_cap, xl.ilist); ENSURE(c->istart, uint32_t, S0 + 1, xl.istart); ENSURE(c->ilen, uint32_t, S0 + 1, xl.ilen); ENSURE(c->icap, uint32_t, S0 + 1, xl.icap);
     if (use_lds) rec<d_inc_build>(c, 1u, 0u, E, S0, (const uint32_t*)m.ea, (const uint32_t*)m.eb, xl.istart, xl.ilen, xl.icap, xl.ilist);
     xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);

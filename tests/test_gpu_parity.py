@@ -1048,3 +1048,25 @@ def test_bench_distributed_bookkeeping_with_one_forced_rank(tmp_path):
     assert line["roofline"]["kernel"].startswith("k_batched<d_merge") and line["library"].startswith("f3ds 1.1.0 src:")
     # 160x120 frames are not BASELINE's workload: the line carries no `value`, the rate sits under what_if_value
     assert line["value"] is None and "not the BASELINE workload" in line["invalid"] and line["what_if_value"] > 0
+
+
+@pytest.mark.gpu
+def test_incident_list_pool_regrows_instead_of_failing(P, oracle, monkeypatch):
+    """The merge loop leaves every merged region's incident-edge list in a pool (2 E entries for the initial lists + room for the lists that outgrow their
+    segment).  F3DS_ILIST_SLACK=1 starts with a pool one merge in twenty would fit: the loop stops with the capacity flag, the host reruns the stage with four
+    times the room (several times over), and the result is the oracle's -- as for the leaf pool and the weight-history arrays."""
+    monkeypatch.setenv("F3DS_ILIST_SLACK", "1")
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+    ctx = P.Context(0)
+    for n in ["rgbd_320x240_ghosts", "fixture_launch_flags", "fused_200k_nan_lambda"]:
+        lab = ctx.segment(case_points(P, n), case_params(P, n))
+        assert sha_of(lab) == gold[n]["labels_sha256"], n
+        assert sha_of(ctx.debug("MERGES")) == gold[n]["sha256"]["MERGES"], n
+    ctxs = [P.Context(0) for _ in range(3)]      # a batch in which the frames need different pool sizes
+    frames = [case_points(P, n) for n in ("rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags")]
+    prm = case_params(P, "rgbd_320x240_ghosts")
+    labs = P.segment_batch(ctxs, frames, prm)
+    for f, l in zip(frames, labs):
+        assert np.array_equal(l, oracle.segment(f, prm)[1])
+    for c in ctxs + [ctx]:
+        c.close()
