@@ -196,3 +196,15 @@ int main() {
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert ("adapter ok" in r.stdout) == (P.device_count() > 0)
+
+
+def test_no_register_copies_inside_hand_issued_lds_pipelines():
+    """The fold loops of the merge kernel and the ordered sums of the voxel-normal kernel issue their LDS reads and the matching s_waitcnt by hand (asm volatile).
+    Between a read and its wait the destination registers are not valid yet, which the compiler cannot know: a register copy placed there silently copies stale
+    data (round 4 hit exactly that: an if / else around two read sets made results depend on timing).  tools/check_async_copies.py scans the generated gfx950
+    assembly for such copies; hipcc cross-compiles without a GPU."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([os.path.join(ROOT, "tools", "check_async_copies.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 suspicious copies") >= 6, r.stdout
