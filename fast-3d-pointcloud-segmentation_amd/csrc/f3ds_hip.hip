@@ -107,12 +107,12 @@ const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e 
 // call of the library (f3ds_segment_batch, f3ds_recluster, f3ds_refine_supervoxels) into this per-thread struct -- not per frame on the hot path,
 // where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
 struct Switches {
-    bool split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
+    bool direct_labels = false, copy_stream = true, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
     int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32; long relabel_lds_cap = -1;
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
-        split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
+        direct_labels = num("F3DS_DIRECT_LABELS", 0) != 0; copy_stream = num("F3DS_COPY_STREAM", 1) != 0; split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
         force_global_merge = on("F3DS_FORCE_GLOBAL_MERGE"); no_stream_pool = on("F3DS_NO_STREAM_POOL"); sort_pairs = on("F3DS_SORT_PAIRS");
         host_prof = on("F3DS_HOST_PROF"); trace_err = on("F3DS_TRACE_ERR");
         normals_threads = (int)num("F3DS_NORMALS_THREADS", 0); tile_holes = (uint32_t)num("F3DS_SWEEP_TILE_HOLES", 0);
@@ -147,6 +147,7 @@ struct f3ds_ctx {
     // pinned + device staging for the packed arguments of a batch (owned by the batch's first context)
     unsigned char* h_args[2] = {nullptr, nullptr}; unsigned char* d_args[2] = {nullptr, nullptr}; size_t args_cap = 0;      // two arenas, used in turn: a flush never waits for the stream
     hipEvent_t ev_args[2] = {nullptr, nullptr}; bool args_used[2] = {false, false}; int args_flip = 0;
+    hipEvent_t ev_copy[3] = {nullptr, nullptr, nullptr};      // uploads queued on the device's copy stream / labels ready on the call's stream / downloads done on the copy stream
     DevCounters* d_dcblk = nullptr; DevCounters* h_dcblk = nullptr; size_t dcblk_cap = 0;      // the batch's counters, one slot per frame
     // frame state
     bool have_frame = false;
@@ -847,6 +848,18 @@ int finish_empty(f3ds_ctx* c, hipStream_t st, uint32_t* point_labels, int labels
 // of bench.py's three concurrent batches landed in one queue).  A batch therefore does not run on its first context's
 // stream but on one of four streams per device (GPU_MAX_HW_QUEUES of them if that is set) created back to back --
 // different queues -- and held for the call.
+// ONE stream per device for the host <-> device copies of ALL calls (F3DS_COPY_STREAM=0: every call copies on its own stream, as until round 4).  On this platform a
+// host-to-device and a device-to-host copy that run at the same time get 16 GB/s each where either alone gets 55 (tools/pcie_bw.py); with six calls in flight the uploads of
+// one call (16 MB per frame) kept meeting the label downloads of another (4 MB per frame).  Through one stream the link carries one copy at a time at full rate.  A call's
+// downloads are queued only once its labels exist (the host thread waits for the event first), so the stream never sits blocked behind unfinished compute.
+struct CopyStream { std::mutex m; hipStream_t s = nullptr; };
+CopyStream g_copy_stream[16];
+hipStream_t copy_stream_of(int device) {
+    CopyStream& c = g_copy_stream[device & 15];
+    std::lock_guard<std::mutex> lk(c.m);
+    if (!c.s && hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) c.s = nullptr;
+    return c.s;
+}
 struct BatchStreamPool { std::mutex m; hipStream_t s[8] = {}; bool busy[8] = {}; };
 const int g_batch_stream_count = [] { const char* e = getenv("GPU_MAX_HW_QUEUES"); int n = e ? atoi(e) : 4; return n < 1 ? 1 : (n > 8 ? 8 : n); }();      // one per hardware queue HIP will use
 BatchStreamPool g_batch_streams[16];
@@ -870,6 +883,15 @@ int for_frames(Batch& b, F&& fn) {
 }
 void stage_mark(Batch& b, int i) { (void)hipEventRecord(b.owner->ev[i], b.st); }
 
+// device address of a pinned host buffer (nullptr for pageable memory, which the device cannot reach)
+static uint32_t* pinned_device_alias(uint32_t* host) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }      // (pageable memory: "invalid value", and the error must not stick)
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return (uint32_t*)at.devicePointer;
+}
+
 // cluster stage for the live frames (also the whole of f3ds_recluster)
 int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, const std::vector<int>& index_of, int labels_on_device, bool force_global = false) {
     const int kind = choose_merge_kind(b.fr, force_global);      // one kernel for the whole batch
@@ -879,7 +901,15 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     stage_mark(b, 5);
     if ((rc = for_frames(b, seg_merge)) || (rc = flush(b))) return rc;
     stage_mark(b, 6);
-    for (size_t i = 0; i < b.fr.size(); ++i) b.fr[i]->user_labels = (labels_on_device && labels_of) ? labels_of[index_of[i]] : nullptr;
+    for (size_t i = 0; i < b.fr.size(); ++i) {
+        uint32_t* out = labels_of ? labels_of[index_of[i]] : nullptr;
+        // F3DS_DIRECT_LABELS=1 (experiment, measured and not the default): a host label buffer that is pinned (hipHostMalloc / hipHostRegister) is written by the relabel kernel
+        // itself through its device address instead of a staging buffer + device-to-host copy.  With six calls in flight the pinned-host-in / host-out rate of bench.py
+        // drops from 2 060 to 1 830 Mpoints/s: the kernel holds its workgroups while its stores trickle up the link.
+        if (out && !labels_on_device && g_sw.direct_labels) out = pinned_device_alias(out);
+        else if (!labels_on_device) out = nullptr;
+        b.fr[i]->user_labels = out;
+    }
     {
         const uint32_t cap = g_sw.relabel_lds_cap >= 0 ? (uint32_t)g_sw.relabel_lds_cap : RL_LDS_CAP;      // (tests: 0 forces the two-kernel form)
         bool fits = true;
@@ -888,13 +918,25 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     }
     if ((rc = for_frames(b, seg_labels)) || (rc = flush(b))) return rc;
     stage_mark(b, 7);
-    for (size_t i = 0; i < b.fr.size(); ++i) {
-        f3ds_ctx* c = b.fr[i];
-        uint32_t* out = labels_of ? labels_of[index_of[i]] : nullptr;
-        if (out && !c->user_labels) HIPCHECK(hipMemcpyAsync(out, c->labels.p, (size_t)c->n * 4, hipMemcpyDeviceToHost, b.st));
-        c->user_labels = nullptr;
+    {
+        bool want = false;
+        for (size_t i = 0; i < b.fr.size(); ++i) if (labels_of && labels_of[index_of[i]] && !b.fr[i]->user_labels && b.fr[i]->n) want = true;
+        hipStream_t dl = (want && !labels_on_device && g_sw.copy_stream) ? copy_stream_of(b.fr[0]->device) : nullptr;
+        if (dl) {      // queued on the copy stream only once the labels exist: that stream must never sit blocked behind unfinished compute
+            for (int k = 1; k < 3; ++k) if (!b.owner->ev_copy[k]) HIPCHECK(hipEventCreateWithFlags(&b.owner->ev_copy[k], hipEventDisableTiming));
+            HIPCHECK(hipEventRecord(b.owner->ev_copy[1], b.st));
+            { const double t0 = now_ms(); HIPCHECK(hipEventSynchronize(b.owner->ev_copy[1])); g_t_wait += now_ms() - t0; }
+        }
+        for (size_t i = 0; i < b.fr.size(); ++i) {
+            f3ds_ctx* c = b.fr[i];
+            uint32_t* out = labels_of ? labels_of[index_of[i]] : nullptr;
+            if (out && !c->user_labels && c->n) HIPCHECK(hipMemcpyAsync(out, c->labels.p, (size_t)c->n * 4, hipMemcpyDeviceToHost, dl ? dl : b.st));
+            c->user_labels = nullptr;
+        }
+        if (dl) HIPCHECK(hipEventRecord(b.owner->ev_copy[2], dl));
+        if ((rc = flush_sync(b))) return rc;
+        if (dl) { const double t0 = now_ms(); HIPCHECK(hipEventSynchronize(b.owner->ev_copy[2])); g_t_wait += now_ms() - t0; }
     }
-    if ((rc = flush_sync(b))) return rc;
     {
         // a frame whose merge loop re-weights more edges than its event arrays hold (huge regions of tiny supervoxels)
         // runs the stage again -- it starts from the untouched supervoxel state -- with four times the room
@@ -987,6 +1029,7 @@ void f3ds_destroy(f3ds_ctx* c) {
     if (c->h_grid) (void)hipHostFree(c->h_grid);
     if (c->d_sgrid) (void)hipFree(c->d_sgrid);
     for (int k = 0; k < 2; ++k) { if (c->h_args[k]) (void)hipHostFree(c->h_args[k]); if (c->d_args[k]) (void)hipFree(c->d_args[k]); if (c->ev_args[k]) (void)hipEventDestroy(c->ev_args[k]); }
+    for (auto& e : c->ev_copy) if (e) (void)hipEventDestroy(e);
     if (c->d_dcblk) (void)hipFree(c->d_dcblk);
     if (c->h_dcblk) (void)hipHostFree(c->h_dcblk);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1029,6 +1072,8 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     const int max_depth = (int)(1.8f * prm->seed_res / prm->voxel_res);      // [PCL-recall] SupervoxelClustering::extract
     const uint32_t sweeps = max_depth > 1 ? (uint32_t)(max_depth - 1) : 0u;
     stage_mark(b, 0);
+    hipStream_t up_stream = (!points_on_device && g_sw.copy_stream) ? copy_stream_of(ctxs[0]->device) : nullptr;
+    bool uploaded = false;
     for (int i = 0; i < nctx; ++i) {
         f3ds_ctx* c = ctxs[i];
         c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
@@ -1041,10 +1086,15 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
         if (points_on_device) c->d_pts = (const P16*)points[i];
         else {
             P16* up; ENSURE(c->pts, P16, c->n ? c->n : 1, up);
-            if (c->n) HIPCHECK(hipMemcpyAsync(up, points[i], (size_t)c->n * 16, hipMemcpyHostToDevice, b.st));
+            if (c->n) { HIPCHECK(hipMemcpyAsync(up, points[i], (size_t)c->n * 16, hipMemcpyHostToDevice, up_stream ? up_stream : b.st)); uploaded = true; }
             c->d_pts = up;
         }
         b.fr.push_back(c); index_of.push_back(i);
+    }
+    if (up_stream && uploaded) {      // the call's kernels wait for its uploads, which went through the device's copy stream
+        if (!b.owner->ev_copy[0]) HIPCHECK(hipEventCreateWithFlags(&b.owner->ev_copy[0], hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(b.owner->ev_copy[0], up_stream));
+        HIPCHECK(hipStreamWaitEvent(b.st, b.owner->ev_copy[0], 0));
     }
     auto drop_dead = [&](auto&& dead) -> int {      // frames without voxels leave the batch with all labels = F3DS_NO_LABEL
         std::vector<f3ds_ctx*> keep; std::vector<int> keep_idx;

@@ -1070,3 +1070,42 @@ def test_incident_list_pool_regrows_instead_of_failing(P, oracle, monkeypatch):
         assert np.array_equal(l, oracle.segment(f, prm)[1])
     for c in ctxs + [ctx]:
         c.close()
+
+
+@pytest.mark.gpu
+def test_pinned_host_label_buffers_are_written_by_the_kernel_itself(P, oracle, monkeypatch):
+    """With F3DS_DIRECT_LABELS=1, host label buffers that are pinned (hipHostMalloc) get their labels straight from the relabel kernel through the buffer's
+    device address; by default (and for pageable buffers) they take the staging copy on the device's copy stream, or on the call's own stream with
+    F3DS_COPY_STREAM=0.  Same labels every way, for a batch with an empty frame and for a lone frame."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.1)
+    frames = [P.synth_frame(0, 5200 + i, 200 + 20 * i, 150, 30) for i in range(3)] + [np.zeros((0, 4), np.float32)]
+    want = [oracle.segment(f, prm)[1] for f in frames]
+    bufs = []
+    for f in frames:
+        p = ctypes.c_void_p()
+        assert hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(max(4 * len(f), 64)), 0) == 0
+        bufs.append(p)
+    ctxs = [P.Context(0) for _ in frames]
+    try:
+        for direct in ("direct", "copy stream", "own stream"):
+            monkeypatch.setenv("F3DS_DIRECT_LABELS", "1" if direct == "direct" else "0")
+            monkeypatch.setenv("F3DS_COPY_STREAM", "0" if direct == "own stream" else "1")
+            for p, f in zip(bufs, frames):
+                ctypes.memset(p, 0xAB, max(4 * len(f), 64))
+            arrs = [np.ascontiguousarray(f, np.float32) for f in frames]
+            P.segment_batch(ctxs, [a.ctypes.data for a in arrs], prm, labels_out=[p.value for p in bufs], n=[len(a) for a in arrs], raw_host=True)
+            for p, f, w in zip(bufs, frames, want):
+                got = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint32)), shape=(max(len(f), 1),))[:len(f)]
+                assert np.array_equal(got, w), direct
+        # a lone frame into the pinned buffer, direct path again
+        monkeypatch.setenv("F3DS_DIRECT_LABELS", "1")
+        a = np.ascontiguousarray(frames[1], np.float32)
+        P.segment_batch(ctxs[:1], [a.ctypes.data], prm, labels_out=[bufs[1].value], n=[len(a)], raw_host=True)
+        got = np.ctypeslib.as_array(ctypes.cast(bufs[1], ctypes.POINTER(ctypes.c_uint32)), shape=(len(a),))
+        assert np.array_equal(got, want[1])
+    finally:
+        for c in ctxs:
+            c.close()
+        for p in bufs:
+            hip.hipHostFree(p)
