@@ -576,9 +576,9 @@ int seg_seeds(f3ds_ctx* c) {
     rec_fill(c, chk, 0xFFFFFFFFu, (size_t)ccap * 8);
     const uint32_t* ckey = (const uint32_t*)c->ckey.p; const uint32_t* cell_start = (const uint32_t*)c->cell_start.p; const float* vf = (const float*)c->vf.p;
     rec<d_cell_hash>(c, grid_for(C, 256), 0u, ckey, (const uint32_t*)sorted_vox, cell_start, (const DevCounters*)c->d_dc, chk, chvals, ccap - 1);
-    rec<d_seed_nn>(c, C, 0u, vf, ckey, (const uint32_t*)sorted_vox, cell_start, (const DevCounters*)c->d_dc, (const SeedGrid*)c->d_sgrid, (const uint64_t*)chk, (const uint32_t*)chvals,
+    rec<d_seed_nn>(c, (C + 3u) / 4u, 0u, vf, ckey, (const uint32_t*)sorted_vox, cell_start, (const DevCounters*)c->d_dc, (const SeedGrid*)c->d_sgrid, (const uint64_t*)chk, (const uint32_t*)chvals,
                    ccap - 1, seed_orig);
-    rec<d_seed_filter>(c, C, 0u, vf, ckey, (const uint32_t*)sorted_vox, cell_start, (const DevCounters*)c->d_dc, (const uint64_t*)chk, (const uint32_t*)chvals, ccap - 1,
+    rec<d_seed_filter>(c, (C + 3u) / 4u, 0u, vf, ckey, (const uint32_t*)sorted_vox, cell_start, (const DevCounters*)c->d_dc, (const SeedGrid*)c->d_sgrid, (const uint64_t*)chk, (const uint32_t*)chvals, ccap - 1,
                        (const int*)seed_orig, a_radius_sq(c->prm.seed_res), a_min_points(c->prm.seed_res, c->prm.voxel_res), keep);
     int rc = scan_u32(c, keep, (uint32_t*)c->incl.p, C);
     if (rc) return rc;
