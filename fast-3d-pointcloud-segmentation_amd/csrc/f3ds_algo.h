@@ -143,8 +143,11 @@ struct SweepView {
     const uint32_t* ghost_next;   // S0+1
     const uint32_t* n_ghosts;
     float seed_res, w_normal, w_color, w_spatial;
+    const int* nbr_rows = nullptr;      // V x 27, the same table row-major (optional): a voxel's 27 slots are two lines, not 27 -- for lanes that do NOT hold consecutive voxels
 };
 F3DS_HD int a_nbr(const SweepView& s, int v, int k) { return s.nbrT[(size_t)k * (size_t)s.V + (size_t)v]; }
+// for the work-list kernels (chain walker, marks around a helper's leaves): their lanes hold scattered voxels, and what a gather costs is the lines it touches
+F3DS_HD int a_nbr_w(const SweepView& s, int v, int k) { return s.nbr_rows ? s.nbr_rows[(size_t)v * 27u + (size_t)k] : a_nbr(s, v, k); }
 // feature rows are 48 bytes, 16-byte aligned: three 128-bit loads instead of nine 32-bit ones
 F3DS_HD void a_load_row(const float* p, float out[12]) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -201,7 +204,7 @@ F3DS_HD F3DS_NOINLINE bool a_eval_R_chain(const SweepView& s, int w0, unsigned c
         uint32_t g_cached = 0; bool cached_less = false;
         const bool ghosts_w = ghosts && memo[w] != (unsigned char)(T | F3DS_R_OPEN);      // (the pre-pass vouches for the voxels it marked open)
         for (int k = slot[sp]; k < 27; ++k) {
-            int u = a_nbr(s, w, k);
+            int u = a_nbr_w(s, w, k);
             if (u < 0) continue;
             // a lower helper with a ghost leaf on u always reaches w at its turn
             if (ghosts_w) {
@@ -250,7 +253,7 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
     // (loads are unconditional -- an absent neighbour reads w's own entry -- so that the 27 index loads and
     // then the 27 gathers are each in flight together instead of one round trip per neighbour)
     int nu[27]; uint32_t og[27];
-    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr_w(s, w, k);
     for (int k = 0; k < 27; ++k) {
         const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];
         og[k] = (nu[k] >= 0 && g != 0u && g < h) ? g : 0u;

@@ -624,7 +624,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     }
     const int* nbrT = (const int*)c->nbrT.p; const float* vf = sb.vf;
     SweepFrame a;
-    a.sv = SweepView{(int)V, nbrT, vf, owner0, dist0, hc, ghost_head, ghost_next, (const uint32_t*)&c->d_dc->n_ghosts, prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial};
+    a.sv = SweepView{(int)V, nbrT, vf, owner0, dist0, hc, ghost_head, ghost_next, (const uint32_t*)&c->d_dc->n_ghosts, prm.seed_res, prm.w_normal, prm.w_color, prm.w_spatial, (const int*)c->nbr.p};
     a.R = R; a.ownR = ownR; a.owner_out = owner0; a.dist_out = dist0;
     a.ghost_done = ghost_done; a.ghost_active = ghost_active; a.ghost_vox = ghost_vox; a.ghost_head = ghost_head; a.ghost_next = ghost_next;
     a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
