@@ -76,19 +76,47 @@ F3DS_HD void n_grid_from_bbox(const float mn[3], const float mx[3], float voxel_
 F3DS_HD void n_point_key(const GridInfo& g, float x, float y, float z, int use_transform, unsigned key[3]) {
     n_transform(x, y, z, use_transform);
     if (!use_transform || n_finite3(x, y, z)) {
-        key[0] = (unsigned)(((double)x - g.min[0]) / g.res);
-        key[1] = (unsigned)(((double)y - g.min[1]) / g.res);
-        key[2] = (unsigned)(((double)z - g.min[2]) / g.res);
+        // (unsigned)(a / res) without the division where that is provably the same number: a * (1 / res) is within 2.2e-16 of a / res relatively, the correctly rounded
+        // quotient within 1.1e-16, keys are below 2^21 -- so whenever the product lies more than 1e-6 away from an integer, quotient and product truncate alike.  Only a
+        // coordinate that close to a cell border takes the division (three f64 divisions per point were a third of the key kernel's instructions).
+        const double inv = 1.0 / g.res;
+        const float p[3] = {x, y, z};
+        for (int a = 0; a < 3; ++a) {
+            const double d = (double)p[a] - g.min[a];
+            const double q1 = d * inv;
+            const unsigned k1 = (unsigned)q1;
+            const double f = q1 - (double)k1;
+            key[a] = (f > 1e-6 && f < 1.0 - 1e-6 && q1 < 4194304.0) ? k1 : (unsigned)(d / g.res);
+        }
     } else {
         key[0] = key[1] = key[2] = 0u;     // transformed point not finite -> default OctreeKey
     }
 }
 // depth-first leaf order of the octree = this code ascending (child = x<<2|y<<1|z per level)
+// (bit b of x, y, z -> bits 3b + 2, 3b + 1, 3b, for b < depth: the coordinates' bits spread three apart with the usual mask-and-shift steps instead of a loop over the bits --
+// 32-bit steps up to depth 10, i.e. every frame of a depth camera)
+F3DS_HD uint32_t n_spread3_10(uint32_t v) {        // 10 bits
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+F3DS_HD uint64_t n_spread3_21(uint64_t v) {        // 21 bits
+    v = (v | (v << 32)) & 0x001F00000000FFFFull;
+    v = (v | (v << 16)) & 0x001F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
 F3DS_HD uint64_t n_morton(unsigned x, unsigned y, unsigned z, int depth) {
-    uint64_t c = 0;
-    for (int b = depth - 1; b >= 0; --b)
-        c = (c << 3) | (uint64_t)((((x >> b) & 1u) << 2) | (((y >> b) & 1u) << 1) | ((z >> b) & 1u));
-    return c;
+    if (depth <= 10) {
+        const uint32_t m = (1u << depth) - 1u;
+        return (uint64_t)((n_spread3_10(x & m) << 2) | (n_spread3_10(y & m) << 1) | n_spread3_10(z & m));
+    }
+    const uint64_t m = (1ull << depth) - 1ull;
+    return (n_spread3_21(x & m) << 2) | (n_spread3_21(y & m) << 1) | n_spread3_21(z & m);
 }
 F3DS_HD void n_demorton(uint64_t c, int depth, unsigned key[3]) {
     unsigned x = 0, y = 0, z = 0;
