@@ -131,7 +131,11 @@ int f3ds_segment(f3ds_ctx* ctx, const void* points, size_t n, int points_on_devi
  * dispatch for all frames and all merge loops run as one dispatch.  points[i] / point_labels[i] /
  * counts[i] belong to ctxs[i]; results may be NULL.  Synchronous.  The batch runs on the stream set
  * with f3ds_set_stream on ctxs[0] if there is one, else on one of a few library-owned streams per
- * device (one per hardware queue), so that batch calls from several host threads run side by side. */
+ * device (one per hardware queue), so that batch calls from several host threads run side by side.
+ * Host buffers (points_on_device / labels_on_device == 0): the uploads and downloads of ALL calls on a device go
+ * through one library-owned copy stream, one copy after the other -- the PCIe link moves 55 GB/s one way alone and ~16
+ * each way when uploads and downloads of different calls overlap; the call's kernels wait for its uploads by event.
+ * Pinned (hipHostMalloc) buffers are what makes these copies asynchronous; pageable ones work and are slower. */
 int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, const size_t* counts,
                        int points_on_device, const f3ds_params* params, uint32_t* const* point_labels,
                        int labels_on_device, f3ds_result* results);
