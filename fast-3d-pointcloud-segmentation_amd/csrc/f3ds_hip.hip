@@ -5,8 +5,8 @@
 //   0 voxelise   d_bbox -> d_grid -> d_keys -> radix sort -> d_heads/scan/d_segstart -> d_point_gather -> d_voxel_accum
 //   1 neighbours d_neighbors (hash probe of the 27 cells), d_normals_t<384 | 256 threads> (two-ring ordered covariance, LDS tile)
 //   2 seeds      d_chunkbox, d_seed_grow, d_seed_keys, radix sort, d_cell_hash, d_seed_nn, d_seed_filter
-//   3 sweeps     per sweep: d_sweep_begin, d_sweep_R_round x4 | d_sweep_R_pre + d_sweep_R, d_sweep_claim, d_claim_mark,
-//                d_centroid, d_centroid_mark  
+//   3 sweeps     per sweep: d_sweep_begin, d_sweep_R_first (pre-pass | round 0), d_sweep_R_round x2 | d_sweep_R + d_sweep_R_tail, d_sweep_claim,
+//                d_centroid (both mark dirty tiles on the spot)  
 //   4 summaries  d_sv_fill (payload rows + ordered leaf sums), d_edges, radix sort, d_edge_init,
 //                d_edge_deltas, d_lambda / d_cdf_*, d_edge_weights
 //   5 merge      d_inc_build, d_merge_il_t<4 or 8 waves, per-edge arrays in LDS or L2> (one persistent workgroup per frame), d_merge (global memory)
@@ -178,7 +178,7 @@ struct f3ds_ctx {
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
-    Buf tstamp, tround, hdirty, htiles, htcnt, vchg, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
+    Buf tstamp, tround, hdirty, htiles, htcnt, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, ilist, istart, ilen, icap, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
 };
@@ -606,8 +606,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     uint32_t *tiles4, *trr, *hD;
     ENSURE(c->tstamp, uint32_t, (size_t)4 * T, tiles4); ENSURE(c->tround, uint32_t, (size_t)(F3DS_R_ROUNDS - 1) * T, trr); ENSURE(c->hdirty, uint32_t, S0 + 1, hD);
     uint32_t *tl, *tcnt; ENSURE(*sb.htiles, uint32_t, (size_t)(S0 + 1) * HT_CAP, tl); ENSURE(*sb.htcnt, uint32_t, S0 + 1, tcnt);
-    uint32_t *chg, *wl, *wl2; ENSURE(c->vchg, uint32_t, V, chg); ENSURE(c->vwl, uint32_t, V, wl); ENSURE(c->vwl2, uint32_t, V, wl2);
-    rec_fill(c, chg, 0u, (size_t)V * 4);
+    uint32_t *wl, *wl2; ENSURE(c->vwl, uint32_t, V, wl); ENSURE(c->vwl2, uint32_t, V, wl2);
     rec_fill(c, tiles4, 0u, (size_t)4 * T * 4);
     rec_fill(c, trr, 0u, (size_t)(F3DS_R_ROUNDS - 1) * T * 4);
     rec_fill(c, hD, 0u, (size_t)(S0 + 1) * 4);
@@ -628,7 +627,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     a.R = R; a.ownR = ownR; a.owner_out = owner0; a.dist_out = dist0;
     a.ghost_done = ghost_done; a.ghost_active = ghost_active; a.ghost_vox = ghost_vox; a.ghost_head = ghost_head; a.ghost_next = ghost_next;
     a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
-    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.chg = chg; a.wl = wl; a.wl2 = wl2;
+    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.wl = wl; a.wl2 = wl2;
     a.thr = g_inc_shift >= 32 ? 0xFFFFFFFFu : (g_inc_shift < 0 ? 0u : V >> g_inc_shift);
     if (!g_sw.sweep_tiles) a.tile_n1 = nullptr;      // development: F3DS_SWEEP_TILES=0 keeps the sweeps on their global-gather path (A/B, tests)
     else a.tile_n1 = (const uint32_t*)c->tile_n1.p;
@@ -639,14 +638,13 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
         // (sweeps 0 and 1 are full by construction -- d_sweep_begin: marking starts after a sweep t >= 1 at the earliest, and a sweep skips tiles only if the one
         // before it was marking --, so their incremental launches would be no-ops on every frame: not recorded)
         const bool can_skip = t >= 2u;
-        if (g_inc_shift >= 0 && can_skip) for (uint32_t r = 0; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
-        rec<d_sweep_R_pre>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t);
+        const bool rounds = g_inc_shift >= 0 && can_skip;
+        rec<d_sweep_R_first>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t, rounds ? 1u : 0u);      // pre-pass of a full sweep | round 0 of an incremental one
+        if (rounds) for (uint32_t r = 1; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
         for (uint32_t pass = 0; pass < F3DS_R_PASSES; ++pass) rec<d_sweep_R>(c, pass == 0 ? grid_for(V, 256) : 64u, 0u, a, a_sweep_tag(t), t, pass);
         rec<d_sweep_R_tail>(c, 1u, 0u, a, a_sweep_tag(t), t);
         rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
-        if (g_inc_shift >= 0 && t >= 1u) rec<d_claim_mark>(c, grid_for(V, 256), 0u, a, t);      // (sweep 0 never marks)
         rec<d_centroid>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
-        if (g_inc_shift >= 0 && t >= 1u) rec<d_centroid_mark>(c, grid_for((size_t)S0 * 64u, 256), 0u, a, t);
     }
     return F3DS_OK;
 }
