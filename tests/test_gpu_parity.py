@@ -136,6 +136,34 @@ def test_edge_cases(P, oracle, gpu_ctx):
         gpu_ctx.segment(cases["tiny_plane"], P.launch_params(voxel_res=0.02, seed_res=0.2, merging=0, lambda_=1.5))
 
 
+def test_points_on_cell_borders_get_the_reference_keys(P, oracle, emul, gpu_ctx):
+    """Voxel keys are (unsigned)((x - min) / res) in double.  The key kernel multiplies by 1 / res wherever the product provably truncates like the quotient and divides
+    only within 1e-6 of a cell border (csrc/f3ds_numerics.h, n_point_key): a lattice of points exactly ON the borders (and one ulp to either side) takes the division
+    path on nearly every coordinate; voxel keys, counts and labels must still be the oracle's bits -- also for a resolution whose reciprocal is inexact, and at depth > 10
+    (the 64-bit Morton interleave)."""
+    rng = np.random.default_rng(5)
+    for res, span in ((0.008, 40), (0.013, 30), (0.002, 1400)):
+        r32 = np.float32(res)
+        i = rng.integers(0, span, (6000, 3)).astype(np.float32)
+        base = (i * r32).astype(np.float32)                                  # on (or within a rounding of) a border
+        nudge = rng.integers(-1, 2, base.shape)
+        pts3 = np.where(nudge < 0, np.nextafter(base, np.float32(-1e9)), np.where(nudge > 0, np.nextafter(base, np.float32(1e9)), base)).astype(np.float32)
+        pts3[:, 2] += np.float32(0.5)
+        pts = np.zeros((len(pts3), 4), np.float32); pts[:, :3] = pts3
+        pts[:, 3] = rng.integers(0, 2**24, len(pts)).astype(np.uint32).view(np.float32)
+        prm = P.launch_params(voxel_res=res, seed_res=res * 8)
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        assert rc == 0
+        rc2, elab, eres, eh = emul.segment(pts, prm)
+        assert rc2 == 0 and np.array_equal(olab, elab)
+        glab = gpu_ctx.segment(pts, prm)
+        assert gpu_ctx.result.octree_depth == ores.octree_depth
+        for k in ("VOXEL_KEYS", "VOXEL_COUNT"):
+            assert same_bits(oh.get(k), gpu_ctx.debug(k)), (res, k)
+        assert np.array_equal(olab, glab), res
+    assert ores.octree_depth > 10
+
+
 def test_device_pointers_and_streams(P, oracle, gpu_ctx):
     """Caller-owned device buffers (torch tensors) in, labels out on the device, on a torch stream."""
     torch = pytest.importorskip("torch")
