@@ -18,6 +18,9 @@ every step runs the complete path; nothing is cached between steps.
 every rank runs its own 64 frames per step (weak scaling, no data-path collective); the label
 output of a step is ONE RCCL gather of the step's [64, 1M] uint32 label block to rank 0, issued in
 step order from a dedicated thread while later steps run.
+``--strong``: BASELINE config 5 as literally written instead -- ONE batch of 64 frames (seeds 1000..1063) per step for the whole
+job, frame i on rank i mod N (64 / N frames per rank and step), the step's label blocks gathered to rank 0 in ONE RCCL gather;
+`scaling` is then "strong" and `value` still the whole job's points per second.
 
 The JSON line also carries
   value              -- whole-job Mpoints/s with the frames resident in HBM when the timed region starts and the
@@ -29,7 +32,7 @@ The JSON line also carries
   config5_batch_latency_ms -- BASELINE config 5 as literally stated, from an idle GPU: wall time of ONE batch of 64 frames
                         as one call on one GPU (the N=1 shape) and of ONE call of 8 frames (what each GPU runs at N=8);
   roofline           -- the dominant kernel is the merge loop (k_batched<d_merge_*>: first by total kernel time in the
-                        rocprofv3 trace of this same command, profiles/r4_kernel_stats.csv); its launch duration is
+                        rocprofv3 trace of this same command, the newest profiles/r*_kernel_stats.csv); its launch duration is
                         measured live by a pair of HIP events around that one dispatch on the call's stream inside
                         libf3ds (f3ds_result.ms_stage[5]) and averaged over the timed region's calls.  achieved =
                         20 B/point x points per launch / mean launch duration, against the 8 TB/s HBM3E peak;
@@ -68,9 +71,40 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1000)
     ap.add_argument("--host-io-steps", type=int, default=-1, help="steps of the pinned-host-in / host-out pass (default min(steps, 12); 0 = skip)")
     ap.add_argument("--host-io-groups", type=int, default=0, help="batch calls in flight in the host-in / host-out pass (0 = as --groups): a call is longer there by its PCIe copies")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: one 64-frame batch per step for the whole job, frame i on rank i mod N (BASELINE config 5 as written); default: weak, 64 frames per step on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-latency", action="store_true", help="no lone-frame / one-batch latency runs after the timed region (profile runs: only the timed loop's launches in the trace)")
     return ap.parse_args()
+
+
+def cpu_baseline_record(npts, cpu_s, sm_s, main_s, libm_same, host_cpus):
+    """The `cpu_baseline` object of the JSON line from the oracle's timings (one frame, one core).  The baseline is timed on the libm-linked
+    build; a label vector that differs from the shared-math build's (the parity checker) voids it: value null, reason stated."""
+    cpu = {"value": round(npts / cpu_s / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+           "sample": "1 frame (%d points) of the same workload through oracle/libf3ds_oracle_libm.so (libm transcendentals), %.2f s" % (npts, cpu_s),
+           "labels_equal_shared_math_build": bool(libm_same),
+           "shared_math_build": {"value": round(npts / sm_s / 1e6, 4), "seconds": round(sm_s, 2), "what": "the same frame through oracle/libf3ds_oracle.so (the bit-parity checker: transcendentals of csrc/f3ds_math.h)"},
+           "as_main_runs_it": {"value": round(npts / main_s / 1e6, 4), "seconds": round(main_s, 2),
+                               "what": "label path + refineSupervoxels(3) + a second VCCS extract (the truth cloud), as main() does per file"},
+           "note": "the port is faster than the reference would be: hash-set contains() instead of the O(E) scan, cached mean_color",
+           "host_cpus": host_cpus}
+    if not libm_same:
+        cpu["value"] = None
+        cpu["as_main_runs_it"]["value"] = None
+        cpu["invalid"] = "the libm-linked oracle's labels differ from the shared-math oracle's on this frame"
+    return cpu
+
+
+def strong_estimate(batch_latency, npts):
+    """What ONE 64-frame batch (config 5 as written) would take on N GPUs, from this GPU's own measurements -- an estimate, not a measurement: no
+    multi-GPU node has run it.  At N = 8 every GPU runs one call of 8 frames (`one_call_of_8_frames`, measured here from an idle GPU); the label
+    gather (8 x 4 MB per peer over its own xGMI link, ~0.2 ms) is not in it."""
+    if not batch_latency:
+        return None
+    b64, b8 = batch_latency["one_batch_of_64_frames_one_gpu"], batch_latency["one_call_of_8_frames"]
+    return {"n1_ms_measured": b64, "n8_ms_estimated": b8, "speedup_8_gpus_estimated": round(b64 / b8, 2) if b8 > 0 else None,
+            "mpoints_per_s_n8_estimated": round(FRAMES_PER_STEP * npts / b8 / 1e3, 1) if b8 > 0 else None,
+            "what": "lone-batch latency of config 5 as written; UNMEASURED on hardware for N > 1 (1-GPU pool): a lone call's merge loop (~30 ms) does not shrink with fewer frames per GPU"}
 
 
 def spawn_ranks(args):
@@ -131,10 +165,17 @@ def main():
     if os.environ.get("F3DS_BENCH_THRESHOLD"):                    # development only: what-if runs (the JSON line then names the threshold)
         prm.threshold = float(os.environ["F3DS_BENCH_THRESHOLD"])
     npts = args.width * args.height
-    FPS = FRAMES_PER_STEP
+    if args.strong:      # config 5 as written: the step's 64 frames sharded i mod N
+        if FRAMES_PER_STEP % world:
+            raise SystemExit("bench.py --strong: %d ranks do not divide the batch of %d frames" % (world, FRAMES_PER_STEP))
+        mine = B.frames_of_rank(FRAMES_PER_STEP, rank, world)
+        FPS = len(mine)                                   # frames of a step THIS rank runs
+        seeds = [1000 + i for i in mine]
+    else:                # weak: every rank its own 64 distinct frames per step
+        FPS = FRAMES_PER_STEP
+        seeds = [1000 + rank * FPS + i for i in range(FPS)]
 
-    # 64 distinct synthetic frames per rank -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
-    seeds = [1000 + rank * FPS + i for i in range(FPS)]
+    # the rank's distinct synthetic frames -> HBM (torch owns the device buffers; libf3ds gets raw pointers)
     with ThreadPoolExecutor(8) as ex:
         frames_host = list(ex.map(lambda s: P.synth_frame(0, s, args.width, args.height, 30), seeds))
     frames_dev = [torch.from_numpy(f).to(dev) for f in frames_host]
@@ -293,7 +334,7 @@ def main():
             times.append((time.perf_counter() - t1) * 1e3)
         return sorted(times[1:])[1]
     batch_latency = None
-    if nbatch >= FPS and not args.skip_latency:
+    if nbatch >= FRAMES_PER_STEP and FPS == FRAMES_PER_STEP and not args.skip_latency:      # (a --strong rank at N > 1 holds fewer than 64 frames)
         b64, b8 = one_call_ms(FPS), one_call_ms(8)
         batch_latency = {"one_batch_of_64_frames_one_gpu": round(b64, 3), "one_call_of_8_frames": round(b8, 3),
                          "mpoints_per_s_64": round(FPS * npts / b64 / 1e3, 1), "mpoints_per_s_8": round(8 * npts / b8 / 1e3, 1),
@@ -304,26 +345,25 @@ def main():
         value = world * total_frames * npts / elapsed / 1e6
         mean_stage = [m / max(1, calls_done[0]) for m in stage_ms]       # per batched launch sequence
         frames_per_launch = frames_done[0] / max(1, calls_done[0])
-        # The dominant KERNEL, from what this run measured: the merge loop and the voxel normals are each ONE launch per call and timed on their own
-        # (f3ds_result.ms_stage[5]: HIP events on the call's stream around the merge dispatch; ms_stage[7]: the normals launch's execution window on the
-        # device clock, first workgroup started .. last one ended -- an event pair around that dispatch also counts the 10-15 ms it waits at the head of its
-        # queue for a compute unit with 72 KB of LDS free, which a kernel trace does not); the other stages are sequences of many launches of several
-        # kernels (their per-kernel split is in profiles/r3_kernel_stats*.csv) and are reported as stages below.
+        # The dominant KERNEL: the merge loop is ONE launch per call and timed on its own (f3ds_result.ms_stage[5]: a HIP event pair on the call's stream around
+        # that dispatch).  The other stages are sequences of many launches of several kernels (per-kernel split: the newest profiles/r*_kernel_stats*.csv) and
+        # are reported as stages below; ms_stage[7], the event pair around the voxel-normal dispatch, also counts the time that dispatch waits at the head of
+        # its queue for a compute unit with room for its first workgroup, so it is listed among the stages and never used to rank kernels.
         # (which merge kernel: the library takes the 4-wave layout for a call that shares the device with other batch calls, the 8-wave one otherwise; asked of every
         # call group's context after the timed region (above) -- what its LAST call ran -- and the most frequent answer names the kernel)
         layouts = merge_layouts
         lay = max(layouts, key=layouts.get) if layouts else (8, 2)
         merge_name = "k_batched<d_merge_il_t<%d,%d>>" % lay if lay[0] else "k_batched<d_merge>"
         KERNELS = {5: (merge_name, "merge", "d_merge_il_t"), 7: ("k_batched<d_normals_t<%d>>" % (256 if nbatch >= 16 else 384), "neighbours+normals", "d_normals_t")}      # (256 threads per tile in calls of >= 16 frames)
-        # the merge loop is the first kernel by total time in the kernel trace of this command (profiles/r4_kernel_stats.csv), and the one kernel whose
-        # event pair brackets exactly one dispatch; the voxel-normal launch's pair is reported beside it (dominant_by), it includes that dispatch's wait for a unit
+        # the merge loop is the first kernel by total time in the kernel trace of this command (the newest profiles/r*_kernel_stats.csv), and the one kernel whose
+        # event pair brackets exactly one dispatch
         dom = 5
         dom_ms = mean_stage[dom]
         alg_launch = ALG_BYTES_PER_POINT * npts * frames_per_launch
         achieved = alg_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = path_traffic = path_traffic_min = None
         pmc_file = None
-        for cand in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):      # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
+        for cand in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):      # HBM bytes from the committed PMC passes of this same command (profiles/, tools/pmc_summary.py)
             if os.path.exists(os.path.join(ROOT, "profiles", cand)):
                 pmc_file = cand
                 break
@@ -349,7 +389,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "launch_ms": round(dom_ms, 4), "frames_per_launch": round(frames_per_launch, 2),
                     "algorithmic_bytes_per_launch": int(alg_launch),
-                    "dominant_by": "first kernel by total time in the rocprofv3 kernel trace of this command (profiles/); HIP-event totals of this run: %s" % ", ".join("%s %.1f ms" % (KERNELS[j][2], stage_ms[j]) for j in KERNELS),
+                    "dominant_by": "first kernel by total time in the rocprofv3 kernel trace of this command (profiles/, newest r*_kernel_stats.csv); HIP-event total of its launches in this run: %.1f ms" % stage_ms[dom],
                     "timer": "hipEventRecord pair around the one merge dispatch of every call, on the call's stream (f3ds_result.ms_stage[5]), mean over the timed region's %d calls" % calls_done[0],
                     "merge_layouts_last_call": {"%d waves, residency %d" % k: v for k, v in layouts.items()},
                     "whole_path": whole,
@@ -377,20 +417,11 @@ def main():
             # second VCCS run on the label-coloured cloud (/root/reference/src/supervoxel_clustering.cpp:369-400)
             tm = time.perf_counter()
             oh.refine(3)
-            if not libm_same:
-                cpu["value"] = None; cpu["invalid"] = "the libm-linked oracle's labels differ from the shared-math oracle's on this frame"
             p0 = prm.copy(); p0.threshold = 0.0
             rc2, _, _, oh2 = ora.segment(frames_host[1], p0)
             main_s = cpu_s + time.perf_counter() - tm
             oh2.close()
-            cpu = {"value": round(npts / cpu_s / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
-                   "sample": "1 frame (%d points) of the same workload through oracle/libf3ds_oracle_libm.so (libm transcendentals), %.2f s" % (npts, cpu_s),
-                   "labels_equal_shared_math_build": libm_same,
-                   "shared_math_build": {"value": round(npts / sm_s / 1e6, 4), "seconds": round(sm_s, 2), "what": "the same frame through oracle/libf3ds_oracle.so (the bit-parity checker: transcendentals of csrc/f3ds_math.h)"},
-                   "as_main_runs_it": {"value": round(npts / main_s / 1e6, 4), "seconds": round(main_s, 2),
-                                       "what": "label path + refineSupervoxels(3) + a second VCCS extract (the truth cloud), as main() does per file"},
-                   "note": "the port is faster than the reference would be: hash-set contains() instead of the O(E) scan, cached mean_color",
-                   "host_cpus": os.cpu_count()}
+            cpu = cpu_baseline_record(npts, cpu_s, sm_s, main_s, libm_same, os.cpu_count())
             oh.close()
             # the fair multi-core number (SURVEY.md 8d iii): the 64-frame batch of the step, one frame per host core (the oracle is
             # single-threaded like the reference; ctypes releases the GIL, so these are real threads on real cores)
@@ -401,7 +432,7 @@ def main():
                 done = list(ex.map(lambda f: ora.segment(f, prm)[0], frames_host))
             par_s = time.perf_counter() - tp
             assert all(r == 0 for r in done)
-            cpu["frames_parallel"] = {"value": round(FPS * npts / par_s / 1e6, 4), "unit": "Mpoints/s", "cores": nthr, "host_cpus": ncores, "seconds": round(par_s, 2),
+            cpu["frames_parallel"] = {"value": round(FPS * npts / par_s / 1e6, 4) if libm_same else None, "unit": "Mpoints/s", "cores": nthr, "host_cpus": ncores, "seconds": round(par_s, 2),
                                       "sample": "the %d frames of one step, one frame per core on %d threads through oracle/libf3ds_oracle_libm.so (label path only)" % (FPS, nthr)}
         invalid = None
         what_if = {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_FAKE_MERGE", "F3DS_FAKE_MERGE_LDS") if os.environ.get(k)}
@@ -421,14 +452,16 @@ def main():
             value = None
         line = {"metric": "Mpoints/sec segmented end-to-end, 1M-pt RGB-D frames", "value": round(value, 3) if value is not None else None, "invalid": invalid, "unit": "Mpoints/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "step = batch of %d distinct synthetic %dx%d (%d-point) XYZRGBA frames per GPU (BASELINE config 5's batch, seeds 1000+64*rank..), "
-                                       "-v 0.008 -s 0.08 --AL --CVX -t %g, frames resident in HBM" % (FPS, args.width, args.height, npts, prm.threshold),
+                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": ("step = ONE batch of %d distinct synthetic %dx%d (%d-point) XYZRGBA frames for the whole job, frame i on rank i mod N (BASELINE config 5 as written, seeds 1000..1063), "
+                                        "-v 0.008 -s 0.08 --AL --CVX -t %g, frames resident in HBM" % (world * FPS, args.width, args.height, npts, prm.threshold)) if args.strong else
+                                       ("step = batch of %d distinct synthetic %dx%d (%d-point) XYZRGBA frames per GPU (BASELINE config 5's batch, seeds 1000+64*rank..), "
+                                        "-v 0.008 -s 0.08 --AL --CVX -t %g, frames resident in HBM" % (FPS, args.width, args.height, npts, prm.threshold)),
                            "frames_per_step_per_gpu": FPS, "points_per_step": world * FPS * npts, "frames_timed": world * total_frames,
                            "batch_calls": len(plan), "frames_per_call": round(total_frames / max(1, len(plan)), 1), "concurrent_calls": ngroups, "distinct_frames_per_gpu": FPS,
                            "setup": "two untimed passes over all contexts (scratch allocation up to the high-water marks of the 64 frames) before the warm-up steps",
-                           "parallelism": ("%d ranks, one per GPU, every rank its own frames" % world) if world > 1 else "1 GPU",
-                           "label_gather": "one RCCL gather of each step's [64, 1M] label block (256 MB per rank) to rank 0, in step order, overlapped with later steps" if dist_on else "none (1 rank)",
+                           "parallelism": ("%d ranks, one per GPU, %s" % (world, "frame i of every step on rank i mod N" if args.strong else "every rank its own frames")) if world > 1 else "1 GPU",
+                           "label_gather": ("one RCCL gather of each step's [%d, 1M] label block (%d MB per rank) to rank 0, in step order, overlapped with later steps" % (FPS, FPS * 4)) if dist_on else "none (1 rank)",
                            "V": res.n_voxels, "S": res.n_supervoxels, "E": res.n_edges, "merges": res.n_merges, "regions": res.n_regions},
                 "what_if": what_if or None, "what_if_value": round(what_if_value, 3) if what_if else None,
                 "value_hbm_resident": round(value, 3) if value is not None else None,
@@ -436,6 +469,7 @@ def main():
                 "value_note": "`value`: frames resident in HBM, labels left in HBM (the bench contract: a PCIe-inclusive rate is never `value`); `value_survey_8d` = `value_host_io.value`: "
                               "pinned host buffer in -> labels in a pinned host buffer, the metric as SURVEY.md 8d words it",
                 "value_host_io": host_io, "labels_checked": parity, "single_frame_latency_ms": round(latency_ms, 3), "config5_batch_latency_ms": batch_latency,
+                "strong_scaling_estimate": strong_estimate(batch_latency, npts),
                 "library": lib_text, "roofline": roofline, "cpu_baseline": cpu}
     for grp in ctxs:
         for c in grp:

@@ -74,6 +74,12 @@ class Result(ctypes.Structure):
         return d
 
 
+class SupervoxelSet(ctypes.Structure):
+    """f3ds_supervoxel_set (include/f3ds.h): the supervoxel_clusters map of the reference as plain arrays."""
+    _fields_ = [("n_supervoxels", ctypes.c_uint32), ("label", ctypes.c_void_p), ("voxel_offset", ctypes.c_void_p), ("voxel_xyz", ctypes.c_void_p),
+                ("voxel_rgba", ctypes.c_void_p), ("centroid_xyz", ctypes.c_void_p), ("normal", ctypes.c_void_p)]
+
+
 _lib = None
 
 
@@ -126,6 +132,10 @@ def load_library(path=None):
     lib.f3ds_get_voxel_cloud.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_voxel_cloud.restype = ctypes.c_int
     lib.f3ds_get_debug.argtypes = [vp, ctypes.c_int, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_debug.restype = ctypes.c_int
     lib.f3ds_get_region_adjacency.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_region_adjacency.restype = ctypes.c_int
+    lib.f3ds_cluster_supervoxels.argtypes = [vp, ctypes.POINTER(SupervoxelSet), vp, sz, ctypes.POINTER(Params), vp, vp, ctypes.POINTER(Result)]
+    lib.f3ds_cluster_supervoxels.restype = ctypes.c_int
+    lib.f3ds_get_regions.argtypes = [vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_regions.restype = ctypes.c_int
+    lib.f3ds_get_region_voxels.argtypes = [vp, vp, vp, vp, sz, ctypes.POINTER(sz)]; lib.f3ds_get_region_voxels.restype = ctypes.c_int
     lib.f3ds_multi_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]; lib.f3ds_multi_create.restype = ctypes.c_int
     lib.f3ds_multi_destroy.argtypes = [vp]; lib.f3ds_multi_destroy.restype = None
     lib.f3ds_multi_devices.argtypes = [vp]; lib.f3ds_multi_devices.restype = ctypes.c_int
@@ -177,7 +187,7 @@ def source_stamp():
 
 
 def library_stamp(lib=None):
-    """The stamp the loaded libf3ds.so was built from (f3ds_version_string: 'f3ds 1.1.0 src:<stamp>[ +whatif]')."""
+    """The stamp the loaded libf3ds.so was built from (f3ds_version_string: 'f3ds 1.2.0 src:<stamp>[ +whatif]')."""
     text = (lib or load_library()).f3ds_version_string().decode()
     return text.split("src:")[1].split()[0], text
 
@@ -194,7 +204,7 @@ def check_library_is_current(lib=None):
 
 
 (OK, ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_DEPTH, ERR_LOGIC, ERR_RANGE, ERR_UNSUPPORTED, ERR_IO, ERR_EQ_BIN,
- ERR_CAPACITY, ERR_BUSY, ERR_EMPTY) = (0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11, -12)       # include/f3ds.h:37-52
+ ERR_CAPACITY, ERR_BUSY, ERR_EMPTY, ERR_OUT_OF_RANGE) = (0, -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11, -12, -13)       # include/f3ds.h:37-56
 
 
 def _check(lib, rc):
@@ -207,7 +217,23 @@ def _check(lib, rc):
         raise LogicError(rc, text)
     if rc == -6:
         raise ValueError(text)
+    if rc == -13:
+        raise IndexError(text)      # std::out_of_range of the reference (map::at, all_thresh bounds)
     raise F3dsError(rc, text)
+
+
+def pack_supervoxels(segm):
+    """{label: dict(voxels_xyz (n,3) f32, voxels_rgba (n,) u32, centroid (3,), normal (3,))} -- the shape of the reference's
+    ``std::map<uint32_t, pcl::Supervoxel::Ptr>`` -- -> dict of the arrays f3ds_supervoxel_set points at (rows in the dict's own order)."""
+    labels = np.array(list(segm.keys()), np.uint32)
+    counts = [len(np.asarray(segm[k]["voxels_xyz"]).reshape(-1, 3)) for k in segm]
+    off = np.zeros(len(labels) + 1, np.uint32)
+    off[1:] = np.cumsum(counts)
+    xyz = np.concatenate([np.asarray(segm[k]["voxels_xyz"], np.float32).reshape(-1, 3) for k in segm]) if len(labels) else np.zeros((0, 3), np.float32)
+    rgba = np.concatenate([np.asarray(segm[k]["voxels_rgba"], np.uint32).reshape(-1) for k in segm]) if len(labels) else np.zeros(0, np.uint32)
+    cent = np.array([np.asarray(segm[k]["centroid"], np.float32)[:3] for k in segm], np.float32).reshape(-1, 3)
+    nrm = np.array([np.asarray(segm[k]["normal"], np.float32)[:3] for k in segm], np.float32).reshape(-1, 3)
+    return dict(label=labels, voxel_offset=off, voxel_xyz=np.ascontiguousarray(xyz), voxel_rgba=np.ascontiguousarray(rgba), centroid_xyz=cent, normal=nrm)
 
 
 def default_params(**kw):
@@ -391,6 +417,41 @@ class Context:
         pairs = np.zeros((n.value, 2), np.uint32)
         _check(self.lib, self.lib.f3ds_get_region_adjacency(self.handle, pairs.ctypes.data, n.value, ctypes.byref(n)))
         return pairs
+
+    def cluster_supervoxels(self, sv, adjacency_pairs, params):
+        """f3ds_cluster_supervoxels: Clustering::set_initialstate(segm, adj) + cluster(threshold) on caller-supplied supervoxels.
+        ``sv``: dict of arrays label, voxel_offset, voxel_xyz, voxel_rgba, centroid_xyz, normal (see pack_supervoxels);
+        ``adjacency_pairs``: (P, 2) uint32 in multimap iteration order.  Returns (region_of_sv, voxel_labels)."""
+        a = {k: np.ascontiguousarray(sv[k], np.float32 if k in ("voxel_xyz", "centroid_xyz", "normal") else np.uint32) for k in
+             ("label", "voxel_offset", "voxel_xyz", "voxel_rgba", "centroid_xyz", "normal")}
+        S = len(a["label"])
+        st = SupervoxelSet(S, *[a[k].ctypes.data for k in ("label", "voxel_offset", "voxel_xyz", "voxel_rgba", "centroid_xyz", "normal")])
+        pairs = np.ascontiguousarray(adjacency_pairs, np.uint32).reshape(-1, 2)
+        nvox = int(a["voxel_offset"][S]) if S and len(a["voxel_offset"]) > S else 0
+        region = np.zeros(S, np.uint32); vlab = np.zeros(nvox, np.uint32)
+        _check(self.lib, self.lib.f3ds_cluster_supervoxels(self.handle, ctypes.byref(st), pairs.ctypes.data, len(pairs), ctypes.byref(params), region.ctypes.data,
+                                                           vlab.ctypes.data, ctypes.byref(self.result)))
+        self._n = nvox
+        return region, vlab
+
+    def regions(self):
+        """get_currentstate().first: dict of arrays label, n_voxels, xyz (centroid_), normal (normal_), rgb (mean_color) per merged region, ascending key."""
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_regions(self.handle, None, None, None, None, None, 0, ctypes.byref(n)))
+        k = n.value
+        out = dict(label=np.zeros(k, np.uint32), n_voxels=np.zeros(k, np.uint32), xyz=np.zeros((k, 3), np.float32), normal=np.zeros((k, 3), np.float32),
+                   rgb=np.zeros((k, 3), np.float32))
+        _check(self.lib, self.lib.f3ds_get_regions(self.handle, out["label"].ctypes.data, out["n_voxels"].ctypes.data, out["xyz"].ctypes.data, out["normal"].ctypes.data,
+                                                   out["rgb"].ctypes.data, k, ctypes.byref(n)))
+        return out
+
+    def region_voxels(self):
+        """The regions' voxels_ clouds concatenated in the order of regions(): (xyz, rgba, voxel index)."""
+        n = ctypes.c_size_t()
+        _check(self.lib, self.lib.f3ds_get_region_voxels(self.handle, None, None, None, 0, ctypes.byref(n)))
+        xyz = np.zeros((n.value, 3), np.float32); rgba = np.zeros(n.value, np.uint32); idx = np.zeros(n.value, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_region_voxels(self.handle, xyz.ctypes.data, rgba.ctypes.data, idx.ctypes.data, n.value, ctypes.byref(n)))
+        return xyz, rgba, idx
 
     def voxel_cloud(self):
         n = ctypes.c_size_t()
@@ -729,9 +790,19 @@ class Clustering:
     def get_bins_num(self):
         return self.bins_num
 
-    def set_initialstate(self, supervoxels):
-        """Takes the SupervoxelClustering object (its extract() result lives on the device)."""
-        self._super = supervoxels
+    def set_initialstate(self, segm, adj=None, context=None):
+        """set_initialstate(segm, adj) (clustering.cpp:605-612).  Two forms:
+        * ``segm`` = {label: dict(voxels_xyz, voxels_rgba, centroid, normal)}, ``adj`` = iterable of (first, second) in multimap
+          iteration order -- supervoxels of ANY algorithm, as the reference's signature takes them (f3ds_cluster_supervoxels);
+        * ``segm`` = a SupervoxelClustering object, ``adj`` omitted -- its extract() result is already device-resident."""
+        if adj is None and isinstance(segm, SupervoxelClustering):
+            self._super, self._user = segm, None
+            self._segmented = False
+            return
+        if adj is None:
+            raise TypeError("set_initialstate(segm, adj): the adjacency map is missing")
+        self._user = (pack_supervoxels(segm), np.array(list(adj), np.uint32).reshape(-1, 2), context or Context())
+        self._super = _UserState(self._user[2])
         self._segmented = False
 
     def _params(self, threshold):
@@ -746,7 +817,10 @@ class Clustering:
         if self._super is None:
             raise LogicError(-5, "Cannot call 'cluster' before setting an initial state with 'set_initialstate'")
         ctx = self._super.ctx
-        if not self._segmented:
+        if not self._segmented and getattr(self, "_user", None):
+            self._region_of_sv, self._labels = ctx.cluster_supervoxels(self._user[0], self._user[1], self._params(threshold))
+            self._segmented = True
+        elif not self._segmented:
             self._labels = ctx.segment(self._super.cloud, self._params(threshold))
             self._segmented = True
         else:
@@ -755,14 +829,21 @@ class Clustering:
             self.lambda_ = ctx.result.lambda_
 
     def all_thresh(self, truth_point_labels, start_thresh, end_thresh, step_thresh):      # clustering.cpp:691-741
-        """{threshold: performanceSet dict} over the sweep; the state is left clustered at best_thresh of it."""
+        """{threshold: performanceSet dict} over the sweep.  As in the reference the state is left clustered at the LAST threshold of the
+        sweep (:718-726); IndexError (std::out_of_range, :694-698) for bounds outside [0, 1]; start > end are swapped (:699-705)."""
         if self._super is None:
             raise LogicError(-5, "Cannot call 'all_thresh' before setting an initial state with 'set_initialstate'")
+        if getattr(self, "_user", None):
+            raise LogicError(-5, "all_thresh needs the frame's points (ground truth is per input point): use a SupervoxelClustering state")
+        if start_thresh < 0 or start_thresh > 1 or end_thresh < 0 or end_thresh > 1 or step_thresh < 0 or step_thresh > 1:
+            raise IndexError("start_thresh, end_thresh and/or step_thresh outside of range [0, 1]")
         ctx = self._super.ctx
         if not self._segmented:
-            ctx.segment(self._super.cloud, self._params(start_thresh if 0 <= start_thresh <= 1 else 0.0))
+            ctx.segment(self._super.cloud, self._params(min(start_thresh, end_thresh)))
             self._segmented = True
         bt, bp, table, self._labels = ctx.auto_threshold(self._params(0.0), truth_point_labels, start_thresh, end_thresh, step_thresh)
+        if table:
+            self._labels = ctx.recluster(self._params(max(table)))      # (f3ds_auto_threshold leaves the context at the best threshold: main()'s use)
         if self.merging_type == ADAPTIVE_LAMBDA:
             self.lambda_ = ctx.result.lambda_
         return table
@@ -788,5 +869,29 @@ class Clustering:
         return xyz, rgba
 
     def get_point_labels(self):
-        """Per input point region id (the composition with pcl getLabeledCloud)."""
+        """Per input point region id (the composition with pcl getLabeledCloud); per input VOXEL after
+        set_initialstate(segm, adj)."""
         return self._labels
+
+    def get_currentstate(self):                    # clustering.cpp:619-624
+        """(segments, adjacency): segments = {label: dict(voxels_xyz, voxels_rgba, voxel_index, centroid, normal, mean_rgb)} of the merged
+        regions (state.segments), adjacency = (K, 2) array of label pairs a < b (weight2adj(state.weight_map))."""
+        ctx = self._super.ctx
+        r = ctx.regions()
+        xyz, rgba, idx = ctx.region_voxels()
+        segm, o = {}, 0
+        for k in range(len(r["label"])):
+            n = int(r["n_voxels"][k])
+            segm[int(r["label"][k])] = dict(voxels_xyz=xyz[o:o + n], voxels_rgba=rgba[o:o + n], voxel_index=idx[o:o + n], centroid=r["xyz"][k],
+                                            normal=r["normal"][k], mean_rgb=r["rgb"][k])
+            o += n
+        return segm, ctx.region_adjacency()
+
+
+class _UserState:
+    """What Clustering keeps in place of a SupervoxelClustering object after set_initialstate(segm, adj)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.params = default_params()
+        self.cloud = None

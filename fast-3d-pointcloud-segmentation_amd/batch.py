@@ -52,6 +52,17 @@ def gather_label_block(block, dist, bufs=None, dst=0):
     return bufs if rank == dst else None
 
 
+def assemble_strong(bufs):
+    """Strong scaling (bench.py --strong, BASELINE config 5 as written): a step is ONE batch whose frame i ran on rank i mod N, so after
+    the step's gather block r holds the global frames r, r + N, r + 2N, ...  Returns the [frames, points] block in global frame order."""
+    import torch
+    world = len(bufs)
+    out = torch.empty((world * bufs[0].shape[0],) + tuple(bufs[0].shape[1:]), dtype=bufs[0].dtype, device=bufs[0].device)
+    for r, b in enumerate(bufs):
+        out[r::world] = b
+    return out
+
+
 def plan_batches(total_frames, max_batch, groups, ramp=False):
     """Cut `total_frames` consecutive frames into batch calls of at most `max_batch` frames.  Returns [(first, last+1), ...].
 

@@ -108,7 +108,7 @@ const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e 
 // where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
 struct Switches {
     bool direct_labels = false, copy_stream = true, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
-    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32; long relabel_lds_cap = -1;
+    int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32, r_rounds = F3DS_R_ROUNDS; long relabel_lds_cap = -1;
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
         auto num = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
@@ -119,6 +119,7 @@ struct Switches {
         { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 4 ? 4 : (v ? 8 : 0); }
         { const char* e = getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
         relabel_lds_cap = num("F3DS_RELABEL_LDS_CAP", -1);
+        { const long v = num("F3DS_R_ROUNDS_RUN", F3DS_R_ROUNDS); r_rounds = v >= 1 && v <= F3DS_R_ROUNDS ? (uint32_t)v : (uint32_t)F3DS_R_ROUNDS; }
         { const long v = num("F3DS_ILIST_SLACK", 32); ilist_slack = v >= 1 && v <= 32 ? (uint32_t)v : 32u; }      // tests: a short incident-list pool (the merge stage then reruns with a larger one)
     }
 };
@@ -165,6 +166,7 @@ struct f3ds_ctx {
     int merge_kind = 0;                // which merge kernel the last cluster stage ran (MergeKind)
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
+    uint32_t ilist_mult = 1;           // incident-list pool size factor (its own: a leaf-pool overflow must not grow the list pool too)
     uint32_t edge_mult = 32;           // adjacency list room per seed (S0 * edge_mult + 1024), grown on demand
     bool relabel_lds = true;           // stage 6 as one kernel (the region-id table fits LDS for every frame of the batch)
     int refined_itr = -1;              // >= 0: the r_* buffers hold the state after that many refinement iterations of this frame
@@ -179,8 +181,13 @@ struct f3ds_ctx {
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
     Buf tstamp, tround, hdirty, htiles, htcnt, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
+    Buf u_src, u_voff, u_xyz, u_rgba, u_cent, u_nrm;      // f3ds_cluster_supervoxels: the caller's supervoxels as uploaded
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, ilist, istart, ilen, icap, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
+    // f3ds_cluster_supervoxels: the state is caller-supplied supervoxels (no points, no voxel grid).  user_label[h] = the caller's label of internal
+    // supervoxel h (h = rank in ascending label + 1; [0] = 0), user_row[h] = its row in the caller's arrays; empty after f3ds_segment
+    bool user_mode = false;
+    std::vector<uint32_t> user_label, user_row;
 };
 
 namespace {
@@ -639,8 +646,9 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
         // before it was marking --, so their incremental launches would be no-ops on every frame: not recorded)
         const bool can_skip = t >= 2u;
         const bool rounds = g_inc_shift >= 0 && can_skip;
-        rec<d_sweep_R_first>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t, rounds ? 1u : 0u);      // pre-pass of a full sweep | round 0 of an incremental one
-        if (rounds) for (uint32_t r = 1; r < F3DS_R_ROUNDS; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r);
+        const uint32_t nrounds = rounds ? g_sw.r_rounds : 0u;      // (F3DS_R_ROUNDS; F3DS_R_ROUNDS_RUN=1|2 lets tests reach the non-convergence fallback of d_sweep_R)
+        rec<d_sweep_R_first>(c, grid_for(V, 256), 0u, a, a_sweep_tag(t), t, nrounds);      // pre-pass of a full sweep | round 0 of an incremental one
+        for (uint32_t r = 1; r < nrounds; ++r) rec<d_sweep_R_round>(c, grid_for(V, 256), 0u, a, t, r, nrounds);
         for (uint32_t pass = 0; pass < F3DS_R_PASSES; ++pass) rec<d_sweep_R>(c, pass == 0 ? grid_for(V, 256) : 64u, 0u, a, a_sweep_tag(t), t, pass);
         rec<d_sweep_R_tail>(c, 1u, 0u, a, a_sweep_tag(t), t);
         rec<d_sweep_claim>(c, grid_for(V, 256), 0u, a, t);
@@ -759,8 +767,15 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
     ENSURE(c->pool, uint2, xl.pool_cap, xl.pool); ENSURE(c->rstart, uint32_t, S0 + 1, xl.rstart); ENSURE(c->rnleaf, uint32_t, S0 + 1, xl.rnleaf);
     ENSURE(c->rcap, uint32_t, S0 + 1, xl.rcap);
     // incident-edge lists of the regions (d_inc_build): the initial lists take 2 E entries, a merge whose touched list outgrows a's segment takes a fresh one
-    { const uint64_t cap = 2ull * E + (uint64_t)g_sw.ilist_slack * E * c->pool_mult + (g_sw.ilist_slack < 32u ? 16u : 1024u); xl.ilist_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap; }
-    ENSURE(c->ilist, uint32_t, xl.ilist_cap, xl.ilist); ENSURE(c->istart, uint32_t, S0 + 1, xl.istart); ENSURE(c->ilen, uint32_t, S0 + 1, xl.ilen); ENSURE(c->icap, uint32_t, S0 + 1, xl.icap);
+    // (only the incident-list kernels have them: d_merge, the all-global fallback of the large-E scenes, scans the edge arrays.  What the loop can need is bounded: a
+    // merge that leaves its segment takes at most nt + nt / 2 + 4 fresh entries, nt <= MC_TL_CAP, and there are at most S0 - 1 merges)
+    if (use_lds) {
+        const uint64_t bound = 2ull * E + (uint64_t)(S0 ? S0 - 1u : 0u) * (MC_TL_CAP + MC_TL_CAP / 2u + 4u) + 1024u;
+        uint64_t cap = 2ull * E + (uint64_t)g_sw.ilist_slack * E * c->ilist_mult + (g_sw.ilist_slack < 32u ? 16u : 1024u);
+        if (cap > bound) cap = bound;
+        xl.ilist_cap = cap > 0x7fffffffull ? 0x7fffffffu : (uint32_t)cap;
+        ENSURE(c->ilist, uint32_t, xl.ilist_cap, xl.ilist); ENSURE(c->istart, uint32_t, S0 + 1, xl.istart); ENSURE(c->ilen, uint32_t, S0 + 1, xl.ilen); ENSURE(c->icap, uint32_t, S0 + 1, xl.icap);
+    }
     if (use_lds) rec<d_inc_build>(c, 1u, 0u, E, S0, (const uint32_t*)m.ea, (const uint32_t*)m.eb, xl.istart, xl.ilen, xl.icap, xl.ilist);
     xl.stop_key = (prm->threshold != prm->threshold) ? 0u : n_weight_key(prm->threshold);
     c->merge_in_lds = use_lds; c->merge_kind = kind;
@@ -942,6 +957,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
         for (f3ds_ctx* c : b.fr) {
             if (c->h_dc->ev_overflow == 1 && c->ev_mult < 16384u) { c->ev_mult *= 4u; again = true; }
             if (c->h_dc->ev_overflow == 2 && c->pool_mult < 64u) { c->pool_mult *= 4u; again = true; }
+            if (c->h_dc->ev_overflow == 4 && c->ilist_mult < 4096u) { c->ilist_mult *= 4u; again = true; }
         }
         if (again) {
             if (g_sw.trace_err) fprintf(stderr, "f3ds: merge stage of %zu frames runs again with more history / leaf-pool room\n", b.fr.size());
@@ -1076,6 +1092,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
         f3ds_ctx* c = ctxs[i];
         c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
         c->have_frame = false; c->live = true; c->rc = 0; c->refined_itr = -1;
+        c->user_mode = false; c->user_label.clear(); c->user_row.clear();
         { const int prc = pregrow_scratch(c); if (prc) return prc; }
         c->prm = *prm; c->n = (uint32_t)counts[i]; c->V = c->C = c->S0 = c->E = 0;
         memset(&c->res, 0, sizeof c->res);
@@ -1206,6 +1223,119 @@ int f3ds_recluster(f3ds_ctx* c, const f3ds_params* prm, uint32_t* point_labels, 
     return F3DS_OK;
 }
 
+// Clustering::set_initialstate(segm, adj) + cluster(threshold) on caller-supplied supervoxels (include/f3ds.h).  Host side: the std::map / std::multimap
+// orders the reference iterates in (ascending key; adjacency rows by `first`, insertion order inside) become ranks and an edge list; device side: d_sv_user_fill
+// builds what d_sv_fill builds for the library's own supervoxels, and stages 4c-6 run unchanged.
+int f3ds_cluster_supervoxels(f3ds_ctx* c, const f3ds_supervoxel_set* sv, const uint32_t* pairs, size_t n_pairs, const f3ds_params* prm, uint32_t* region_of_sv,
+                             uint32_t* voxel_labels, f3ds_result* result) {
+    if (!c || !sv || !prm || (n_pairs && !pairs)) return F3DS_ERR_ARG;
+    const uint32_t S = sv->n_supervoxels;
+    if (S && (!sv->label || !sv->voxel_offset || !sv->voxel_xyz || !sv->voxel_rgba || !sv->centroid_xyz || !sv->normal)) return F3DS_ERR_ARG;
+    if (S >= 0x3FFFFFFFu) return F3DS_ERR_UNSUPPORTED;
+    const auto t0 = std::chrono::steady_clock::now();
+    g_sw.read();
+    HIPCHECK(hipSetDevice(c->device));
+    // ---- std::map<uint32_t, Supervoxel::Ptr>: ascending key
+    std::vector<uint32_t> row(S + 1u, 0u), lab(S + 1u, 0u), hof(S, 0u);      // row[h], label[h] of internal supervoxel h = rank + 1; hof[row] = h
+    {
+        std::vector<uint32_t> order(S);
+        for (uint32_t i = 0; i < S; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sv->label[a] < sv->label[b]; });
+        for (uint32_t r = 0; r < S; ++r) {
+            if (r && sv->label[order[r]] == sv->label[order[r - 1]]) return F3DS_ERR_ARG;      // (a map holds a key once)
+            row[r + 1] = order[r]; lab[r + 1] = sv->label[order[r]]; hof[order[r]] = r + 1u;
+        }
+    }
+    if (S && sv->voxel_offset[0] != 0u) return F3DS_ERR_ARG;
+    for (uint32_t i = 0; i < S; ++i) if (sv->voxel_offset[i + 1] <= sv->voxel_offset[i]) return F3DS_ERR_ARG;      // every supervoxel holds a voxel
+    const uint32_t Vt = S ? sv->voxel_offset[S] : 0u;
+    if ((uint64_t)Vt + S + 1u > 0x7fffffffull) return F3DS_ERR_UNSUPPORTED;
+    // ---- clear_adjacency + adj2weight: rows with first <= second, multimap order
+    std::vector<uint32_t> ea, eb;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> ed;      // (h_first, h_second)
+        for (size_t k = 0; k < n_pairs; ++k) {
+            const uint32_t p = pairs[2 * k], q = pairs[2 * k + 1];
+            if (p > q) continue;
+            uint32_t hh[2];
+            for (int w = 0; w < 2; ++w) {
+                const uint32_t l = w ? q : p;
+                const auto it = std::lower_bound(lab.begin() + 1, lab.end(), l);
+                if (it == lab.end() || *it != l) return F3DS_ERR_OUT_OF_RANGE;
+                hh[w] = (uint32_t)(it - lab.begin());
+            }
+            if (hh[0] == hh[1]) return F3DS_ERR_ARG;
+            ed.push_back({hh[0], hh[1]});
+        }
+        std::stable_sort(ed.begin(), ed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+        std::vector<std::pair<uint32_t, uint32_t>> chk(ed);
+        std::sort(chk.begin(), chk.end());
+        for (size_t k = 1; k < chk.size(); ++k) if (chk[k] == chk[k - 1]) return F3DS_ERR_ARG;
+        if (ed.size() > 0x7fffffffull) return F3DS_ERR_UNSUPPORTED;
+        ea.resize(ed.size()); eb.resize(ed.size());
+        for (size_t k = 0; k < ed.size(); ++k) { ea[k] = ed[k].first; eb[k] = ed[k].second; }
+    }
+    const uint32_t E = (uint32_t)ea.size();
+    // ---- frame state
+    c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0;
+    c->have_frame = false; c->live = true; c->rc = 0; c->refined_itr = -1;
+    { const int prc = pregrow_scratch(c); if (prc) return prc; }
+    c->prm = *prm; c->n = Vt; c->V = c->C = 0; c->S0 = S; c->E = E; c->d_pts = nullptr;
+    memset(&c->res, 0, sizeof c->res);
+    c->res.n_voxels = Vt; c->res.n_seeds = S; c->res.n_supervoxels = S; c->res.n_edges = E;
+    c->user_mode = true; c->user_label = lab; c->user_row = row;
+    if (S == 0) {      // an empty map: cluster() finds an empty weight map and returns (src/clustering.cpp:387)
+        c->user_mode = false; c->user_label.clear(); c->user_row.clear(); c->live = false;
+        if (result) *result = c->res;
+        return F3DS_OK;
+    }
+    Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
+    uint32_t *d_src, *d_voff, *d_rgba, *loff, *hcount, *owner, *rcnt0, *ea0, *eb0; float *d_xyz, *d_cent, *d_nrm, *rows, *racc0, *rrec0, *hc; int *row_voxel, *pt_voxel; unsigned char* ralive0;
+    ENSURE(c->u_src, uint32_t, S + 1u, d_src); ENSURE(c->u_voff, uint32_t, S + 1u, d_voff); ENSURE(c->u_xyz, float, (size_t)Vt * 3, d_xyz); ENSURE(c->u_rgba, uint32_t, Vt, d_rgba);
+    ENSURE(c->u_cent, float, (size_t)S * 3, d_cent); ENSURE(c->u_nrm, float, (size_t)S * 3, d_nrm);
+    ENSURE(c->loff, uint32_t, S + 2u, loff); ENSURE(c->hcount, uint32_t, S + 1u, hcount); ENSURE(c->owner0, uint32_t, Vt, owner); ENSURE(c->pt_voxel, int, Vt, pt_voxel);
+    ENSURE(c->rows, float, ((size_t)Vt + S + 1) * 12, rows); ENSURE(c->row_voxel, int, (size_t)Vt + S + 1, row_voxel);
+    ENSURE(c->racc0, float, (size_t)(S + 1) * 12, racc0); ENSURE(c->rcnt0, uint32_t, S + 1u, rcnt0); ENSURE(c->rrec0, float, (size_t)(S + 1) * 16, rrec0);
+    ENSURE(c->ralive0, unsigned char, S + 1u, ralive0); ENSURE(c->hc, float, (size_t)(S + 1) * 12, hc);
+    ENSURE(c->ea0, uint32_t, E, ea0); ENSURE(c->eb0, uint32_t, E, eb0);
+    std::vector<uint32_t> h_loff(S + 2u, 0u), h_cnt(S + 1u, 0u);
+    for (uint32_t h = 1; h <= S; ++h) { h_loff[h] = sv->voxel_offset[row[h]]; h_cnt[h] = sv->voxel_offset[row[h] + 1] - sv->voxel_offset[row[h]]; }
+    h_loff[S + 1] = Vt;      // (rows in use: f3ds_get_voxel_cloud)
+    const hipStream_t st = b.st;
+    HIPCHECK(hipMemcpyAsync(d_src, row.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_voff, sv->voxel_offset, (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_xyz, sv->voxel_xyz, (size_t)Vt * 12, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_rgba, sv->voxel_rgba, (size_t)Vt * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_cent, sv->centroid_xyz, (size_t)S * 12, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(d_nrm, sv->normal, (size_t)S * 12, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(loff, h_loff.data(), (size_t)(S + 2) * 4, hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(hcount, h_cnt.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, st));
+    if (E) { HIPCHECK(hipMemcpyAsync(ea0, ea.data(), (size_t)E * 4, hipMemcpyHostToDevice, st)); HIPCHECK(hipMemcpyAsync(eb0, eb.data(), (size_t)E * 4, hipMemcpyHostToDevice, st)); }
+    stage_mark(b, 4);
+    rec<d_init_counters>(c, 1u, 0u, c->d_dc);
+    rec_fill(c, ralive0, 0u, S + 1u);
+    rec_fill(c, rcnt0, 0u, (size_t)(S + 1) * 4);
+    rec_fill(c, racc0, 0u, 48); rec_fill(c, rrec0, 0u, 64); rec_fill(c, hc, 0u, 48);
+    rec<d_iota>(c, grid_for(Vt, 256), 0u, (uint32_t*)pt_voxel, Vt);
+    rec<d_sv_user_fill>(c, S, 0u, S, (const uint32_t*)d_src, (const uint32_t*)d_voff, (const float*)d_xyz, (const uint32_t*)d_rgba, (const float*)d_cent, (const float*)d_nrm, rows, row_voxel,
+                        owner, racc0, rcnt0, rrec0, ralive0, hc, c->d_dc);
+    int rc = flush(b);
+    if (rc) return rc;
+    uint32_t* lp[1] = {voxel_labels}; std::vector<int> idx{0};
+    if ((rc = run_cluster(b, prm, lp, idx, 0))) return rc;
+    HIPCHECK(hipStreamSynchronize(b.st));
+    for (int k = 4; k < 7; ++k) { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]) == hipSuccess) c->res.ms_stage[k] = ms; }
+    if (region_of_sv) {
+        std::vector<uint32_t> root(S + 1u);
+        HIPCHECK(hipMemcpy(root.data(), c->root.p, (size_t)(S + 1) * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < S; ++i) region_of_sv[i] = lab[root[hof[i]]];
+    }
+    c->live = false;
+    c->res.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (result) *result = c->res;
+    return F3DS_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
@@ -1218,7 +1348,81 @@ int fetch(f3ds_ctx* c, const Buf& b, size_t count, std::vector<T>& out) {
     if (count) HIPCHECK(hipMemcpy(out.data(), b.p, count * sizeof(T), hipMemcpyDeviceToHost));
     return F3DS_OK;
 }
+// label of internal supervoxel h as the caller knows it: h itself after f3ds_segment (helper labels 1..S0), the caller's own after f3ds_cluster_supervoxels
+inline uint32_t label_out(const f3ds_ctx* c, uint32_t h) { return c->user_mode && h < c->user_label.size() ? c->user_label[h] : h; }
+// the leaves of every alive region, in voxels_ concatenation order, as (first payload row, rows)
+int region_leaves(f3ds_ctx* c, std::vector<unsigned char>& ralive, std::vector<std::vector<uint2>>& leaves) {
+    const uint32_t S0 = c->S0;
+    std::vector<uint32_t> rhead, lnext, loff, llen, rstart, rnleaf; std::vector<uint2> pool;
+    int rc;
+    if ((rc = fetch(c, c->ralive, S0 + 1, ralive)) || (rc = fetch(c, c->rhead, S0 + 1, rhead)) || (rc = fetch(c, c->lnext, S0 + 1, lnext)) ||
+        (rc = fetch(c, c->loff, S0 + 2, loff)) || (rc = fetch(c, c->hcount, S0 + 1, llen)))
+        return rc;
+    if (c->merge_in_lds && ((rc = fetch(c, c->pool, c->pool.cap / 8, pool)) || (rc = fetch(c, c->rstart, S0 + 1, rstart)) || (rc = fetch(c, c->rnleaf, S0 + 1, rnleaf)))) return rc;
+    leaves.assign(S0 + 1, {});
+    for (uint32_t h = 1; h <= S0; ++h) {
+        if (!ralive[h]) continue;
+        if (c->merge_in_lds) leaves[h].assign(pool.begin() + rstart[h], pool.begin() + rstart[h] + rnleaf[h]);
+        else for (uint32_t leaf = rhead[h]; leaf; leaf = lnext[leaf]) leaves[h].push_back(make_uint2(loff[leaf], llen[leaf]));
+    }
+    return F3DS_OK;
+}
+// payload rows in use: the library's own supervoxels are packed (loff[S0 + 1] = total); a caller's keep the caller's layout
+inline size_t rows_in_use(const f3ds_ctx* c, const std::vector<uint32_t>& loff) { return c->user_mode ? c->n : loff[c->S0 + 1]; }
 }  // namespace
+
+// get_currentstate().first: the merged regions in ascending key (include/f3ds.h)
+extern "C" int f3ds_get_regions(f3ds_ctx* c, uint32_t* label, uint32_t* n_voxels, float* centroid_xyz, float* normal, float* mean_rgb, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    const uint32_t S0 = c->S0;
+    std::vector<unsigned char> ralive; std::vector<uint32_t> rcnt; std::vector<float> rrec;
+    int rc;
+    if ((rc = fetch(c, c->ralive, S0 + 1, ralive)) || (rc = fetch(c, c->rcnt, S0 + 1, rcnt)) || (rc = fetch(c, c->rrec, (size_t)(S0 + 1) * 16, rrec))) return rc;
+    size_t k = 0;
+    for (uint32_t h = 1; h <= S0; ++h) {
+        if (!ralive[h]) continue;
+        if (k < cap) {
+            const float* r = &rrec[(size_t)h * 16];
+            if (label) label[k] = label_out(c, h);
+            if (n_voxels) n_voxels[k] = rcnt[h];
+            if (centroid_xyz) { centroid_xyz[3 * k] = r[0]; centroid_xyz[3 * k + 1] = r[1]; centroid_xyz[3 * k + 2] = r[2]; }
+            if (normal) { normal[3 * k] = r[3]; normal[3 * k + 1] = r[4]; normal[3 * k + 2] = r[5]; }
+            if (mean_rgb) { mean_rgb[3 * k] = r[6]; mean_rgb[3 * k + 1] = r[7]; mean_rgb[3 * k + 2] = r[8]; }
+        }
+        k++;
+    }
+    if (n_out) *n_out = k;
+    return (k > cap && (label || n_voxels || centroid_xyz || normal || mean_rgb)) ? F3DS_ERR_CAPACITY : F3DS_OK;
+}
+
+extern "C" int f3ds_get_region_voxels(f3ds_ctx* c, float* xyz, uint32_t* rgba, uint32_t* voxel_index, size_t cap, size_t* n_out) {
+    if (!c) return F3DS_ERR_ARG;
+    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    HIPCHECK(hipSetDevice(c->device));
+    HIPCHECK(hipStreamSynchronize(c->stream));
+    std::vector<unsigned char> ralive; std::vector<std::vector<uint2>> leaves; std::vector<float> rows; std::vector<int> rv; std::vector<uint32_t> loff;
+    int rc;
+    if ((rc = region_leaves(c, ralive, leaves)) || (rc = fetch(c, c->loff, c->S0 + 2, loff))) return rc;
+    const size_t nrows = rows_in_use(c, loff);
+    if ((rc = fetch(c, c->rows, nrows * 12, rows)) || (rc = fetch(c, c->row_voxel, nrows, rv))) return rc;
+    size_t k = 0;
+    for (uint32_t h = 1; h <= c->S0; ++h)
+        for (const uint2& leaf : leaves[h])
+            for (uint32_t j = 0; j < leaf.y; ++j) {
+                if (k < cap) {
+                    const float* r = &rows[(size_t)(leaf.x + j) * 12];
+                    if (xyz) { xyz[3 * k] = r[6]; xyz[3 * k + 1] = r[7]; xyz[3 * k + 2] = r[8]; }
+                    if (rgba) rgba[k] = (uint32_t)r[9] << 16 | (uint32_t)r[10] << 8 | (uint32_t)r[11];
+                    if (voxel_index) voxel_index[k] = (uint32_t)rv[leaf.x + j];
+                }
+                k++;
+            }
+    if (n_out) *n_out = k;
+    return (k > cap && (xyz || rgba || voxel_index)) ? F3DS_ERR_CAPACITY : F3DS_OK;
+}
 
 extern "C" int f3ds_get_voxel_cloud(f3ds_ctx* c, float* xyz, uint32_t* label, uint32_t* rgba, size_t cap, size_t* n_out) {
     if (!c) return F3DS_ERR_ARG;
@@ -1226,19 +1430,14 @@ extern "C" int f3ds_get_voxel_cloud(f3ds_ctx* c, float* xyz, uint32_t* label, ui
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     const uint32_t S0 = c->S0;
-    std::vector<unsigned char> ralive; std::vector<uint32_t> rhead, lnext, loff, llen, rstart, rnleaf; std::vector<uint2> pool; std::vector<float> rows;
+    std::vector<unsigned char> ralive; std::vector<std::vector<uint2>> all_leaves; std::vector<uint32_t> loff; std::vector<float> rows;
     int rc;
-    if ((rc = fetch(c, c->ralive, S0 + 1, ralive)) || (rc = fetch(c, c->rhead, S0 + 1, rhead)) || (rc = fetch(c, c->lnext, S0 + 1, lnext)) ||
-        (rc = fetch(c, c->loff, S0 + 2, loff)) || (rc = fetch(c, c->hcount, S0 + 1, llen)))
-        return rc;
-    if (c->merge_in_lds && ((rc = fetch(c, c->pool, c->pool.cap / 8, pool)) || (rc = fetch(c, c->rstart, S0 + 1, rstart)) || (rc = fetch(c, c->rnleaf, S0 + 1, rnleaf)))) return rc;
-    if ((rc = fetch(c, c->rows, (size_t)loff[S0 + 1] * 12, rows))) return rc;
+    if ((rc = region_leaves(c, ralive, all_leaves)) || (rc = fetch(c, c->loff, S0 + 2, loff))) return rc;
+    if ((rc = fetch(c, c->rows, rows_in_use(c, loff) * 12, rows))) return rc;
     size_t k = 0; uint32_t cur = 0;
     for (uint32_t h = 1; h <= S0; ++h) {
         if (!ralive[h]) continue;
-        std::vector<uint2> leaves;      // the region's leaves (first payload row, rows) in voxels_ concatenation order
-        if (c->merge_in_lds) leaves.assign(pool.begin() + rstart[h], pool.begin() + rstart[h] + rnleaf[h]);
-        else for (uint32_t leaf = rhead[h]; leaf; leaf = lnext[leaf]) leaves.push_back(make_uint2(loff[leaf], llen[leaf]));
+        const std::vector<uint2>& leaves = all_leaves[h];      // the region's leaves (first payload row, rows) in voxels_ concatenation order
         for (const uint2& leaf : leaves)
             for (uint32_t j = 0; j < leaf.y; ++j) {
                 if (k < cap) {
@@ -1257,7 +1456,7 @@ extern "C" int f3ds_get_voxel_cloud(f3ds_ctx* c, float* xyz, uint32_t* label, ui
 
 extern "C" int f3ds_get_voxel_centroid_cloud(f3ds_ctx* c, float* xyz, uint32_t* rgba, uint32_t* sv_label, size_t cap, size_t* n_out) {
     if (!c) return F3DS_ERR_ARG;
-    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    if (!c->have_frame || c->user_mode) return F3DS_ERR_LOGIC;      // (caller-supplied supervoxels have no voxel grid)
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     const uint32_t V = c->V;
@@ -1283,7 +1482,7 @@ extern "C" int f3ds_get_supervoxels(f3ds_ctx* c, uint32_t* label, float* xyz, fl
 // reseedSupervoxels; expandSupervoxels(max_depth) }.
 extern "C" int f3ds_refine_supervoxels(f3ds_ctx* c, int num_itr) {
     if (!c || num_itr < 0) return F3DS_ERR_ARG;
-    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    if (!c->have_frame || c->user_mode) return F3DS_ERR_LOGIC;
     g_sw.read();
     HIPCHECK(hipSetDevice(c->device));
     Batch b; b.owner = c; b.st = c->stream; b.fr.push_back(c); g_grid_cap = grid_cap_for_batch(1); g_batch_frames = 1;
@@ -1343,7 +1542,7 @@ int supervoxels_of(f3ds_ctx* c, const Buf& hcount, const Buf& hcent, uint32_t* l
         if (!cnt[h]) continue;
         if (k < cap) {
             const float* r = &hc[(size_t)h * 12];
-            if (label) label[k] = h;
+            if (label) label[k] = label_out(c, h);
             if (xyz) { xyz[3 * k] = r[0]; xyz[3 * k + 1] = r[1]; xyz[3 * k + 2] = r[2]; }
             if (rgb) { rgb[3 * k] = r[3]; rgb[3 * k + 1] = r[4]; rgb[3 * k + 2] = r[5]; }
             if (normal) { normal[3 * k] = r[6]; normal[3 * k + 1] = r[7]; normal[3 * k + 2] = r[8]; }
@@ -1385,7 +1584,7 @@ extern "C" int f3ds_get_supervoxel_adjacency(f3ds_ctx* c, uint32_t* pairs, size_
     std::vector<uint32_t> a, b;
     int rc;
     if ((rc = fetch(c, c->ea0, E, a)) || (rc = fetch(c, c->eb0, E, b))) return rc;
-    for (uint32_t e = 0; e < E; ++e) { pairs[2 * e] = a[e]; pairs[2 * e + 1] = b[e]; }
+    for (uint32_t e = 0; e < E; ++e) { pairs[2 * e] = label_out(c, a[e]); pairs[2 * e + 1] = label_out(c, b[e]); }
     return F3DS_OK;
 }
 
@@ -1410,7 +1609,7 @@ extern "C" int f3ds_get_region_adjacency(f3ds_ctx* c, uint32_t* pairs, size_t ca
     if (n_out) *n_out = keys.size();
     if (!pairs) return F3DS_OK;
     if (cap_pairs < keys.size()) return F3DS_ERR_CAPACITY;
-    for (size_t k = 0; k < keys.size(); ++k) { pairs[2 * k] = (uint32_t)(keys[k] >> 32); pairs[2 * k + 1] = (uint32_t)keys[k]; }
+    for (size_t k = 0; k < keys.size(); ++k) { pairs[2 * k] = label_out(c, (uint32_t)(keys[k] >> 32)); pairs[2 * k + 1] = label_out(c, (uint32_t)keys[k]); }
     return F3DS_OK;
 }
 
@@ -1448,14 +1647,15 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
             if ((rc = fetch(c, c->hcount, S0 + 1, u)) || (rc = fetch(c, c->hc, (size_t)(S0 + 1) * 12, f)) || (rc = fetch(c, c->root, S0 + 1, u2))) return rc;
             for (uint32_t h = 1; h <= S0; ++h) {
                 if (!u[h]) continue;
-                if (what == F3DS_DBG_SV_LABELS) put(&h, 4);
-                else if (what == F3DS_DBG_SV_REGION) put(&u2[h], 4);
+                const uint32_t lh = label_out(c, h), lr = label_out(c, u2[h]);
+                if (what == F3DS_DBG_SV_LABELS) put(&lh, 4);
+                else if (what == F3DS_DBG_SV_REGION) put(&lr, 4);
                 else { float r[10]; for (int k = 0; k < 9; ++k) r[k] = f[(size_t)h * 12 + k]; r[9] = 0.0f; put(r, 40); }
             }
             break;
         case F3DS_DBG_EDGES:
             if ((rc = fetch(c, c->ea0, E, u)) || (rc = fetch(c, c->eb0, E, u2))) return rc;
-            for (uint32_t e = 0; e < E; ++e) { put(&u[e], 4); put(&u2[e], 4); }
+            for (uint32_t e = 0; e < E; ++e) { const uint32_t la = label_out(c, u[e]), lb = label_out(c, u2[e]); put(&la, 4); put(&lb, 4); }
             break;
         case F3DS_DBG_EDGE_DELTAS: if ((rc = fetch(c, c->deltas, (size_t)E * 2, f))) return rc; put(f.data(), f.size() * 4); break;
         case F3DS_DBG_EDGE_WEIGHTS: {
@@ -1470,7 +1670,10 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
             for (uint32_t e = 0; e < E; ++e) { int err = 0; float w = a_tc(mp, f[e * 2], &err) + a_tg(mp, f[e * 2 + 1], &err); put(&w, 4); }
             break;
         }
-        case F3DS_DBG_MERGES: if ((rc = fetch(c, c->merges, (size_t)c->res.n_merges * 3, u))) return rc; put(u.data(), u.size() * 4); break;
+        case F3DS_DBG_MERGES:
+            if ((rc = fetch(c, c->merges, (size_t)c->res.n_merges * 3, u))) return rc;
+            if (c->user_mode) for (size_t k = 0; k + 2 < u.size(); k += 3) { u[k] = label_out(c, u[k]); u[k + 1] = label_out(c, u[k + 1]); }
+            put(u.data(), u.size() * 4); break;
         case F3DS_DBG_VOXEL_REGION:
             if ((rc = fetch(c, c->owner0, V, u)) || (rc = fetch(c, c->root, S0 + 1, u2)) || (rc = fetch(c, c->rincl, S0 + 1, u3))) return rc;
             for (uint32_t v = 0; v < V; ++v) { uint32_t l = u[v] ? u3[u2[u[v]]] - 1u : F3DS_NO_LABEL; put(&l, 4); }
@@ -1544,7 +1747,7 @@ int eval_scores(f3ds_ctx* c, const uint32_t* d_root, const uint32_t* d_incl, uin
 
 extern "C" int f3ds_evaluate(f3ds_ctx* c, const uint32_t* truth_point_labels, f3ds_performance* out) {
     if (!c || !truth_point_labels || !out) return F3DS_ERR_ARG;
-    if (!c->have_frame) return F3DS_ERR_LOGIC;
+    if (!c->have_frame || c->user_mode) return F3DS_ERR_LOGIC;
     HIPCHECK(hipSetDevice(c->device));
     HIPCHECK(hipStreamSynchronize(c->stream));
     int rc = eval_truth(c, truth_point_labels);
@@ -1556,8 +1759,8 @@ extern "C" int f3ds_auto_threshold(f3ds_ctx* c, const f3ds_params* prm, const ui
                                    float* thresholds, f3ds_performance* scores, size_t cap, size_t* n_out, float* best_threshold,
                                    f3ds_performance* best_score, uint32_t* point_labels, int labels_on_device, f3ds_result* result) {
     if (!c || !prm || !truth_point_labels) return F3DS_ERR_ARG;
-    if (!c->have_frame) return F3DS_ERR_LOGIC;
-    if (start < 0 || start > 1 || end < 0 || end > 1 || !(step > 0) || step > 1) return F3DS_ERR_RANGE;   // clustering.cpp:693-700 (step 0 never ends there)
+    if (!c->have_frame || c->user_mode) return F3DS_ERR_LOGIC;
+    if (start < 0 || start > 1 || end < 0 || end > 1 || !(step > 0) || step > 1) return F3DS_ERR_OUT_OF_RANGE;   // std::out_of_range, clustering.cpp:694-698 (step 0 never ends there)
     if (start > end) { float t = start; start = end; end = t; }
     std::vector<float> ts{start};
     for (float t = start + step; t <= end; t += step) ts.push_back(t);

@@ -41,9 +41,9 @@ int f3ds_version(void) { return F3DS_VERSION; }
 // "f3ds <version> src:<stamp>[ +whatif]": the stamp is the hash of the sources this library was built from (csrc/Makefile)
 const char* f3ds_version_string(void) {
 #ifdef F3DS_WHATIF
-    return "f3ds 1.1.0 src:" F3DS_BUILD_STAMP " +whatif";
+    return "f3ds 1.2.0 src:" F3DS_BUILD_STAMP " +whatif";
 #else
-    return "f3ds 1.1.0 src:" F3DS_BUILD_STAMP;
+    return "f3ds 1.2.0 src:" F3DS_BUILD_STAMP;
 #endif
 }
 
@@ -62,6 +62,7 @@ const char* f3ds_strerror(int code) {
         case F3DS_ERR_CAPACITY: return "output buffer too small";
         case F3DS_ERR_BUSY: return "frame pipeline busy";
         case F3DS_ERR_EMPTY: return "frame pipeline empty";
+        case F3DS_ERR_OUT_OF_RANGE: return "out of range: unknown supervoxel label in an adjacency, or threshold bounds outside [0, 1]";
     }
     return "unknown error";
 }

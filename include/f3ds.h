@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define F3DS_VERSION 110
+#define F3DS_VERSION 120
 
 /* label written for points that belong to no region (non-finite input point, or a voxel no
  * supervoxel ever claimed).  The reference never emits such points at all
@@ -50,6 +50,10 @@ extern "C" {
 #define F3DS_ERR_CAPACITY (-10)    /* output buffer too small                                   */
 #define F3DS_ERR_BUSY (-11)        /* frame pipeline: every slot in flight / oldest frame not done yet */
 #define F3DS_ERR_EMPTY (-12)       /* frame pipeline: nothing submitted that has not been taken */
+#define F3DS_ERR_OUT_OF_RANGE (-13) /* std::out_of_range in the reference: an adjacency names a
+                                      supervoxel label that is not in the set (map::at,
+                                      src/clustering.cpp:228-229); all_thresh bounds outside
+                                      [0,1] (:694-698)                                           */
 
 /* enums mirror include/supervoxel_clustering/clustering.h:58-68 */
 enum { F3DS_LAB_CIEDE00 = 0, F3DS_RGB_EUCL = 1 };
@@ -99,7 +103,7 @@ typedef struct f3ds_ctx f3ds_ctx;
 
 void f3ds_default_params(f3ds_params* p);
 int f3ds_version(void);
-/* "f3ds 1.1.0 src:<16 hex digits>": the digits are the SHA-256 prefix of the sources the library was built from
+/* "f3ds 1.2.0 src:<16 hex digits>": the digits are the SHA-256 prefix of the sources the library was built from
  * (csrc/Makefile writes it at build time); tests and bench.py compare it with the sources on disk so that a stale
  * prebuilt libf3ds.so fails loudly.  A library built with the timing experiments compiled in ends in " +whatif". */
 const char* f3ds_version_string(void);
@@ -201,6 +205,53 @@ int f3ds_get_supervoxel_adjacency(f3ds_ctx* ctx, uint32_t* pairs, size_t cap_pai
 /* get_currentstate().second after cluster() (:444): adjacency of the merged regions as sorted pairs (a < b) of the surviving
  * supervoxel labels -- the graph visualize() draws between the centroids of supervoxel_clusters.at(label) (:636-672). */
 int f3ds_get_region_adjacency(f3ds_ctx* ctx, uint32_t* pairs, size_t cap_pairs, size_t* n_out);
+
+/* ---- the merge half on its own: Clustering on supervoxels the CALLER supplies ------------------------------------------
+ * Clustering::set_initialstate(ClusteringT segm, AdjacencyMapT adj) takes "the output of some supervoxel algorithm"
+ * (include/supervoxel_clustering/clustering.h:142, src/clustering.cpp:600-612; main() passes PCL's own supervoxel_clusters
+ * and getSupervoxelAdjacency result, src/supervoxel_clustering.cpp:365,424).  This entry is that call + cluster(threshold)
+ * (src/clustering.cpp:670-679) on plain arrays: a maintainer with PCL runs real PCL supervoxels through the GPU merge loop.
+ *
+ * One f3ds_supervoxel_set row per map entry (pcl::Supervoxel<PointXYZRGBA>): label = the map key (distinct, any u32, any
+ * order: the ascending-key iteration of std::map is rebuilt here); voxels_ = voxel_xyz / voxel_rgba[voxel_offset[i] ..
+ * voxel_offset[i+1]) in the cloud's own order (rgba packed as PCL does, a<<24|r<<16|g<<8|b; only r g b are read:
+ * ColorUtilities::mean_color, src/color_utilities.cpp:117-142); centroid_ (x y z) and normal_ (normal_x/y/z).  Every
+ * supervoxel must hold at least one voxel (PCL emits no empty ones).
+ * adjacency_pairs = the multimap in ITERATION order, n_pairs (first, second) rows; rows with first > second are dropped
+ * (clear_adjacency, :476-486), the rest become the initial weight-map entries in that order (adj2weight: all keys -1, so
+ * insertion order; ties between equal weights later resolve in this order).  Rows are stably sorted by `first` in case the
+ * caller did not iterate a multimap.  F3DS_ERR_OUT_OF_RANGE for an endpoint that is no row of the set (map::at throws
+ * std::out_of_range, :228-229); F3DS_ERR_ARG for a pair listed twice or a self-adjacency (the reference dereferences an
+ * erased supervoxel at the first merge that meets one).
+ * Outputs (either may be NULL): region_of_sv[i] = label of the surviving supervoxel row i ended in (the key it has in
+ * get_currentstate().first); voxel_labels[v] = get_labeled_cloud() id (0..K-1, regions in ascending key) of input voxel v.
+ * Afterwards the context answers f3ds_recluster (other metric / threshold on the same supervoxels), f3ds_get_voxel_cloud,
+ * f3ds_get_regions, f3ds_get_region_voxels, f3ds_get_region_adjacency, f3ds_get_supervoxel_adjacency and the merge-side
+ * F3DS_DBG_* arrays (labels are the caller's); the VCCS-side accessors return F3DS_ERR_LOGIC. */
+typedef struct f3ds_supervoxel_set {
+    uint32_t n_supervoxels;
+    const uint32_t* label;          /* n_supervoxels                                      */
+    const uint32_t* voxel_offset;   /* n_supervoxels + 1, ascending, voxel_offset[0] = 0  */
+    const float* voxel_xyz;         /* 3 per voxel                                        */
+    const uint32_t* voxel_rgba;     /* 1 per voxel                                        */
+    const float* centroid_xyz;      /* 3 per supervoxel                                   */
+    const float* normal;            /* 3 per supervoxel                                   */
+} f3ds_supervoxel_set;
+int f3ds_cluster_supervoxels(f3ds_ctx* ctx, const f3ds_supervoxel_set* sv, const uint32_t* adjacency_pairs, size_t n_pairs,
+                             const f3ds_params* params, uint32_t* region_of_sv, uint32_t* voxel_labels, f3ds_result* result);
+
+/* get_currentstate().first after cluster() (src/clustering.cpp:619-624; read at src/supervoxel_clustering.cpp:443-449): the
+ * merged regions in ascending key.  Per region: its key (label of the surviving supervoxel), number of voxels, centroid_
+ * (computeCentroid of the concatenated voxels_, :412-414), normal_ (:416-425) and the mean colour mean_color() gives.  Any
+ * output may be NULL.  Valid after f3ds_segment / f3ds_recluster / f3ds_cluster_supervoxels. */
+int f3ds_get_regions(f3ds_ctx* ctx, uint32_t* label, uint32_t* n_voxels, float* centroid_xyz, float* normal, float* mean_rgb,
+                     size_t cap, size_t* n_out);
+/* the regions' voxels_ clouds, concatenated in the order of f3ds_get_regions (n_voxels[] splits them), each in the
+ * concatenation order merge() builds (voxels_a ++ voxels_b, :408): position, colour (0x00RRGGBB, the voxel's own, not the
+ * Glasbey colour of f3ds_get_voxel_cloud) and the voxel's index -- leaf ordinal after f3ds_segment (the row of
+ * f3ds_get_voxel_centroid_cloud), input voxel index after f3ds_cluster_supervoxels -- with which the caller gathers any other
+ * per-voxel attribute (Supervoxel::normals_, :409).  Any output may be NULL. */
+int f3ds_get_region_voxels(f3ds_ctx* ctx, float* xyz, uint32_t* rgba, uint32_t* voxel_index, size_t cap, size_t* n_out);
 
 /* ---- evaluation against ground truth and automatic threshold (the path run when -t is omitted) ----
  * Mirrors Testing::eval_performance (src/testing.cpp:239-406) and Clustering::all_thresh / best_thresh

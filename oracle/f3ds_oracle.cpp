@@ -1038,6 +1038,127 @@ int f3ds_oracle_cluster(f3ds_oracle* op, const f3ds_params* prm, uint32_t* label
     return 0;
 }
 
+// Clustering::set_initialstate(segm, adj) + cluster(threshold) on supervoxels the caller supplies (src/clustering.cpp:605-612,
+// 670-679; call site src/supervoxel_clustering.cpp:424): the checker of f3ds_cluster_supervoxels.  The std::map / std::multimap the
+// reference is handed are rebuilt literally from the arrays; argument layout and error codes as in include/f3ds.h.
+int f3ds_oracle_cluster_supervoxels(const f3ds_supervoxel_set* sv, const uint32_t* pairs, size_t n_pairs, const f3ds_params* prm, uint32_t* region_of_sv,
+                                    uint32_t* voxel_labels, f3ds_result* res, f3ds_oracle** handle_out) {
+    if (!sv || !prm || (n_pairs && !pairs)) return F3DS_ERR_ARG;
+    std::unique_ptr<f3ds_oracle> op(new f3ds_oracle);
+    f3ds_oracle& o = *op;
+    o.prm = *prm; o.n = 0;
+    memset(&o.res, 0, sizeof(o.res));
+    const uint32_t S = sv->n_supervoxels;
+    if (S && sv->voxel_offset[0] != 0u) return F3DS_ERR_ARG;
+    for (uint32_t i = 0; i < S; ++i) {
+        if (sv->voxel_offset[i + 1] <= sv->voxel_offset[i]) return F3DS_ERR_ARG;
+        SvPtr s = std::make_shared<Supervoxel>();
+        for (int a = 0; a < 3; ++a) { s->centroid[a] = sv->centroid_xyz[3 * (size_t)i + a]; s->normal[a] = sv->normal[3 * (size_t)i + a]; }
+        for (uint32_t v = sv->voxel_offset[i]; v < sv->voxel_offset[i + 1]; ++v) {
+            const uint32_t c = sv->voxel_rgba[v];
+            s->voxels.push_back(SvPoint{sv->voxel_xyz[3 * (size_t)v], sv->voxel_xyz[3 * (size_t)v + 1], sv->voxel_xyz[3 * (size_t)v + 2], (uint8_t)((c >> 16) & 255), (uint8_t)((c >> 8) & 255), (uint8_t)(c & 255)});
+            s->voxel_idx.push_back((int)v);
+        }
+        s->leaves.push_back(sv->label[i]);
+        if (!o.initial_segments.insert({sv->label[i], s}).second) return F3DS_ERR_ARG;
+    }
+    std::set<std::pair<uint32_t, uint32_t>> seen;
+    for (size_t k = 0; k < n_pairs; ++k) {
+        const uint32_t p = pairs[2 * k], q = pairs[2 * k + 1];
+        o.adjacency.insert({p, q});
+        if (p > q) continue;                                                                     // clear_adjacency drops it before anything reads it
+        if (!o.initial_segments.count(p) || !o.initial_segments.count(q)) return F3DS_ERR_OUT_OF_RANGE;      // segments.at() in init_weights (:228-229)
+        if (p == q || !seen.insert({p, q}).second) return F3DS_ERR_ARG;                          // (the reference dereferences an erased supervoxel at the first merge that meets one)
+    }
+    for (auto& kv : o.initial_segments) o.sv_labels.push_back(kv.first);
+    const uint32_t Vt = S ? sv->voxel_offset[S] : 0u;
+    o.res.n_voxels = Vt; o.res.n_seeds = S; o.res.n_supervoxels = S;
+    int rc = f3ds_oracle_cluster(&o, prm, nullptr, nullptr);
+    if (rc) return rc;
+    if (region_of_sv) {
+        std::map<uint32_t, uint32_t> root_of_leaf;
+        for (auto& kv : o.segments) for (uint32_t leaf : kv.second->leaves) root_of_leaf[leaf] = kv.first;
+        for (uint32_t i = 0; i < S; ++i) region_of_sv[i] = root_of_leaf[sv->label[i]];
+    }
+    if (voxel_labels) {
+        uint32_t cur = 0;
+        for (auto& kv : o.segments) { for (int v : kv.second->voxel_idx) voxel_labels[v] = cur; cur++; }      // get_labeled_cloud numbering (:646-660)
+    }
+    if (res) *res = o.res;
+    if (handle_out) *handle_out = op.release();
+    return 0;
+}
+
+// the supervoxel_clusters map and the getSupervoxelAdjacency multimap of a segmented frame (src/supervoxel_clustering.cpp:356,365) in the
+// array form f3ds_cluster_supervoxels takes: what main() hands to set_initialstate (:424).  voxel_leaf = leaf ordinal of every voxel.
+int f3ds_oracle_export_supervoxels(f3ds_oracle* o, uint32_t* label, uint32_t* voxel_offset, float* voxel_xyz, uint32_t* voxel_rgba, uint32_t* voxel_leaf,
+                                   float* centroid_xyz, float* normal, size_t cap_sv, size_t cap_vox, size_t* n_sv, size_t* n_vox, uint32_t* pairs,
+                                   size_t cap_pairs, size_t* n_pairs) {
+    if (!o) return F3DS_ERR_ARG;
+    size_t k = 0, v = 0;
+    for (auto& kv : o->initial_segments) {
+        const Supervoxel& s = *kv.second;
+        if (k < cap_sv) {
+            if (label) label[k] = kv.first;
+            if (voxel_offset) voxel_offset[k] = (uint32_t)v;
+            for (int a = 0; a < 3; ++a) { if (centroid_xyz) centroid_xyz[3 * k + a] = s.centroid[a]; if (normal) normal[3 * k + a] = s.normal[a]; }
+        }
+        for (size_t j = 0; j < s.voxels.size(); ++j, ++v) {
+            if (v >= cap_vox) continue;
+            const SvPoint& pt = s.voxels[j];
+            if (voxel_xyz) { voxel_xyz[3 * v] = pt.x; voxel_xyz[3 * v + 1] = pt.y; voxel_xyz[3 * v + 2] = pt.z; }
+            if (voxel_rgba) voxel_rgba[v] = (uint32_t)pt.r << 16 | (uint32_t)pt.g << 8 | (uint32_t)pt.b;
+            if (voxel_leaf) voxel_leaf[v] = (uint32_t)s.voxel_idx[j];
+        }
+        k++;
+    }
+    if (voxel_offset && k <= cap_sv && k + 1 <= cap_sv + 1) voxel_offset[k] = (uint32_t)v;      // (voxel_offset holds cap_sv + 1 entries)
+    size_t e = 0;
+    for (auto& kv : o->adjacency) { if (pairs && e < cap_pairs) { pairs[2 * e] = kv.first; pairs[2 * e + 1] = kv.second; } e++; }
+    if (n_sv) *n_sv = k;
+    if (n_vox) *n_vox = v;
+    if (n_pairs) *n_pairs = e;
+    return 0;
+}
+
+// get_currentstate().first (src/clustering.cpp:619-624): the merged regions in ascending key -- layout of f3ds_get_regions / f3ds_get_region_voxels
+int f3ds_oracle_regions(f3ds_oracle* o, uint32_t* label, uint32_t* n_voxels, float* centroid_xyz, float* normal, float* mean_rgb, size_t cap, size_t* n_out) {
+    if (!o) return F3DS_ERR_ARG;
+    size_t k = 0;
+    for (auto& kv : o->segments) {
+        Supervoxel& s = *kv.second;
+        if (k < cap) {
+            if (label) label[k] = kv.first;
+            if (n_voxels) n_voxels[k] = (uint32_t)s.voxels.size();
+            const float* m = mean_color(s);
+            for (int a = 0; a < 3; ++a) {
+                if (centroid_xyz) centroid_xyz[3 * k + a] = s.centroid[a];
+                if (normal) normal[3 * k + a] = s.normal[a];
+                if (mean_rgb) mean_rgb[3 * k + a] = m[a];
+            }
+        }
+        k++;
+    }
+    if (n_out) *n_out = k;
+    return 0;
+}
+int f3ds_oracle_region_voxels(f3ds_oracle* o, float* xyz, uint32_t* rgba, uint32_t* voxel_index, size_t cap, size_t* n_out) {
+    if (!o) return F3DS_ERR_ARG;
+    size_t k = 0;
+    for (auto& kv : o->segments) {
+        const Supervoxel& s = *kv.second;
+        for (size_t j = 0; j < s.voxels.size(); ++j, ++k) {
+            if (k >= cap) continue;
+            const SvPoint& pt = s.voxels[j];
+            if (xyz) { xyz[3 * k] = pt.x; xyz[3 * k + 1] = pt.y; xyz[3 * k + 2] = pt.z; }
+            if (rgba) rgba[k] = (uint32_t)pt.r << 16 | (uint32_t)pt.g << 8 | (uint32_t)pt.b;
+            if (voxel_index) voxel_index[k] = (uint32_t)s.voxel_idx[j];
+        }
+    }
+    if (n_out) *n_out = k;
+    return 0;
+}
+
 int f3ds_oracle_voxel_cloud(f3ds_oracle* o, float* xyz, uint32_t* label, uint32_t* rgba, size_t cap, size_t* n_out) {
     if (!o) return F3DS_ERR_ARG;
     size_t k = 0; uint32_t cur = 0;
@@ -1342,8 +1463,8 @@ extern "C" int f3ds_oracle_auto_threshold(f3ds_oracle* o, const f3ds_params* prm
                                           float step_thresh, float* thresholds, f3ds_performance* scores, size_t cap, size_t* n_out, float* best_t,
                                           f3ds_performance* best_p, uint32_t* labels) {
     if (!o || !prm || !truth_point_labels) return F3DS_ERR_ARG;
-    if (start_thresh < 0 || start_thresh > 1 || end_thresh < 0 || end_thresh > 1 || step_thresh < 0 || step_thresh > 1) return F3DS_ERR_RANGE;
-    if (!(step_thresh > 0)) return F3DS_ERR_RANGE;      // the reference's loop never ends with a zero step; both sides refuse it
+    if (start_thresh < 0 || start_thresh > 1 || end_thresh < 0 || end_thresh > 1 || step_thresh < 0 || step_thresh > 1) return F3DS_ERR_OUT_OF_RANGE;      // std::out_of_range (:694-698)
+    if (!(step_thresh > 0)) return F3DS_ERR_OUT_OF_RANGE;      // the reference's loop never ends with a zero step; both sides refuse it
     if (start_thresh > end_thresh) std::swap(start_thresh, end_thresh);
     std::vector<LPoint> truth = truth_cloud(*o, truth_point_labels);
     std::map<float, f3ds_performance> all;

@@ -61,6 +61,22 @@ class CpuChecker:
                                 ctypes.c_void_p(labels.ctypes.data), ctypes.byref(res), ctypes.byref(h))
         return rc, labels, res, Handle(self, h)
 
+    def cluster_supervoxels(self, sv, pairs, params):
+        """f3ds_oracle_cluster_supervoxels: set_initialstate(segm, adj) + cluster(threshold) on caller-supplied supervoxels (arrays as
+        Context.cluster_supervoxels takes them).  Returns (rc, region_of_sv, voxel_labels, result, handle)."""
+        P = self.P
+        a = {k: np.ascontiguousarray(sv[k], np.float32 if k in ("voxel_xyz", "centroid_xyz", "normal") else np.uint32) for k in
+             ("label", "voxel_offset", "voxel_xyz", "voxel_rgba", "centroid_xyz", "normal")}
+        S = len(a["label"])
+        st = P.SupervoxelSet(S, *[a[k].ctypes.data for k in ("label", "voxel_offset", "voxel_xyz", "voxel_rgba", "centroid_xyz", "normal")])
+        pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        nvox = int(a["voxel_offset"][S]) if S else 0
+        region = np.zeros(S, np.uint32); vlab = np.zeros(nvox, np.uint32)
+        res = P.Result(); h = ctypes.c_void_p()
+        rc = self.fn("cluster_supervoxels")(ctypes.byref(st), ctypes.c_void_p(pairs.ctypes.data), ctypes.c_size_t(len(pairs)), ctypes.byref(params),
+                                            ctypes.c_void_p(region.ctypes.data), ctypes.c_void_p(vlab.ctypes.data), ctypes.byref(res), ctypes.byref(h))
+        return rc, region, vlab, res, Handle(self, h)
+
 
 class Handle:
     def __init__(self, chk, h):
@@ -112,6 +128,42 @@ class Handle:
         assert rc == 0
         k = k.value
         return dict(voxel_label=vl, voxel_normal=vn, label=lab[:k], xyz=feat[:k, 0:3], rgb=feat[:k, 3:6], normal=feat[:k, 6:9], n_voxels=cnt[:k])
+
+    def export_supervoxels(self):
+        """The supervoxel_clusters map + getSupervoxelAdjacency multimap of the frame, in the array form f3ds_cluster_supervoxels takes
+        (what main() hands to set_initialstate, supervoxel_clustering.cpp:424).  Returns (dict of arrays incl. voxel_leaf, pairs)."""
+        fn = self.chk.fn("export_supervoxels")
+        ns, nv, npairs = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        z = ctypes.c_size_t(0)
+        assert fn(self.h, None, None, None, None, None, None, None, z, z, ctypes.byref(ns), ctypes.byref(nv), None, z, ctypes.byref(npairs)) == 0
+        S, V, E = ns.value, nv.value, npairs.value
+        sv = dict(label=np.zeros(S, np.uint32), voxel_offset=np.zeros(S + 1, np.uint32), voxel_xyz=np.zeros((V, 3), np.float32), voxel_rgba=np.zeros(V, np.uint32),
+                  voxel_leaf=np.zeros(V, np.uint32), centroid_xyz=np.zeros((S, 3), np.float32), normal=np.zeros((S, 3), np.float32))
+        pairs = np.zeros((E, 2), np.uint32)
+        vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+        assert fn(self.h, vp(sv["label"]), vp(sv["voxel_offset"]), vp(sv["voxel_xyz"]), vp(sv["voxel_rgba"]), vp(sv["voxel_leaf"]), vp(sv["centroid_xyz"]), vp(sv["normal"]),
+                  ctypes.c_size_t(S), ctypes.c_size_t(V), ctypes.byref(ns), ctypes.byref(nv), vp(pairs), ctypes.c_size_t(E), ctypes.byref(npairs)) == 0
+        return sv, pairs
+
+    def regions(self):
+        """get_currentstate().first as Context.regions() returns it."""
+        fn = self.chk.fn("regions")
+        n = ctypes.c_size_t()
+        assert fn(self.h, None, None, None, None, None, ctypes.c_size_t(0), ctypes.byref(n)) == 0
+        k = n.value
+        out = dict(label=np.zeros(k, np.uint32), n_voxels=np.zeros(k, np.uint32), xyz=np.zeros((k, 3), np.float32), normal=np.zeros((k, 3), np.float32),
+                   rgb=np.zeros((k, 3), np.float32))
+        vp = lambda a: ctypes.c_void_p(a.ctypes.data)
+        assert fn(self.h, vp(out["label"]), vp(out["n_voxels"]), vp(out["xyz"]), vp(out["normal"]), vp(out["rgb"]), ctypes.c_size_t(k), ctypes.byref(n)) == 0
+        return out
+
+    def region_voxels(self):
+        fn = self.chk.fn("region_voxels")
+        n = ctypes.c_size_t()
+        assert fn(self.h, None, None, None, ctypes.c_size_t(0), ctypes.byref(n)) == 0
+        xyz = np.zeros((n.value, 3), np.float32); rgba = np.zeros(n.value, np.uint32); idx = np.zeros(n.value, np.uint32)
+        assert fn(self.h, ctypes.c_void_p(xyz.ctypes.data), ctypes.c_void_p(rgba.ctypes.data), ctypes.c_void_p(idx.ctypes.data), ctypes.c_size_t(n.value), ctypes.byref(n)) == 0
+        return xyz, rgba, idx
 
     def voxel_cloud(self):
         n = ctypes.c_size_t()

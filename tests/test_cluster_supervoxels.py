@@ -1,0 +1,375 @@
+"""The merge half on its own: Clustering::set_initialstate(ClusteringT segm, AdjacencyMapT adj) + cluster(threshold) on supervoxels the
+CALLER supplies (/root/reference/include/supervoxel_clustering/clustering.h:142, src/clustering.cpp:600-612, 670-679; call site
+src/supervoxel_clustering.cpp:424) = f3ds_cluster_supervoxels, and get_currentstate() (:619-624) = f3ds_get_regions / f3ds_get_region_voxels /
+f3ds_get_region_adjacency.
+
+CPU tests pin the oracle's entry (f3ds_oracle_cluster_supervoxels) to the oracle's own whole-frame run; the GPU tests feed the ORACLE's
+supervoxels + adjacency (what main() hands to set_initialstate) through the HIP merge loop and compare every merge-side array bit for bit."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits_equal, canon, first_mismatch
+from golden_cases import case_params, case_points
+
+CASES = ["rgbd_160x120", "rgbd_320x240_ghosts", "fixture_launch_flags"]
+MERGE_ARRAYS = ["SV_LABELS", "EDGES", "EDGE_DELTAS", "EDGE_WEIGHTS", "MERGES", "SV_REGION"]
+
+
+def oracle_frame(oracle, P, name):
+    pts, prm = case_points(P, name), case_params(P, name)
+    rc, labels, res, h = oracle.segment(pts, prm)
+    assert rc == 0
+    sv, pairs = h.export_supervoxels()
+    return pts, prm, labels, res, h, sv, pairs
+
+
+def relabel(sv, pairs, rng):
+    """The same supervoxels under other keys (a strictly increasing map into sparse u32 values, so std::map order is kept) with the rows in another order."""
+    S = len(sv["label"])
+    gaps = rng.integers(1, 1 << 19, S).astype(np.uint64)
+    new_of_rank = (np.cumsum(gaps) + 12345).astype(np.uint32)
+    order = np.argsort(sv["label"], kind="stable")
+    lut = dict(zip(sv["label"][order].tolist(), new_of_rank.tolist()))
+    perm = rng.permutation(S)
+    cnt = np.diff(sv["voxel_offset"]).astype(np.int64)
+    off = np.zeros(S + 1, np.uint32); off[1:] = np.cumsum(cnt[perm])
+    vox = np.concatenate([np.arange(sv["voxel_offset"][i], sv["voxel_offset"][i + 1]) for i in perm]).astype(np.int64)
+    out = dict(label=np.array([lut[int(sv["label"][i])] for i in perm], np.uint32), voxel_offset=off, voxel_xyz=sv["voxel_xyz"][vox], voxel_rgba=sv["voxel_rgba"][vox],
+               centroid_xyz=sv["centroid_xyz"][perm], normal=sv["normal"][perm])
+    new_pairs = np.array([[lut[int(a)], lut[int(b)]] for a, b in pairs], np.uint32).reshape(-1, 2)
+    return out, new_pairs, lut, perm, vox
+
+
+def map_labels(a, lut):
+    return np.array([lut[int(x)] for x in a.reshape(-1)], np.uint32).reshape(a.shape)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: the checker itself
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_merge_only_entry_equals_the_whole_frame_run(oracle, P, name):
+    """set_initialstate(segm, adj) + cluster() on the exported supervoxel map gives what the frame's own clustering gave: same edges, deltas,
+    weights, merges, surviving labels, labelled cloud and regions."""
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, name)
+    rc, region, vlab, res2, h2 = oracle.cluster_supervoxels(sv, pairs, prm)
+    assert rc == 0
+    for what in MERGE_ARRAYS:
+        assert first_mismatch(what, h2.get(what), h.get(what)) is None
+    assert np.array_equal(region, h.get("SV_REGION")) and (res2.n_merges, res2.n_regions, res2.n_edges) == (res.n_merges, res.n_regions, res.n_edges)
+    assert bits_equal(np.float32(res2.lambda_), np.float32(res.lambda_))
+    for a, b in zip(h2.voxel_cloud(), h.voxel_cloud()):
+        assert bits_equal(a, b)
+    r2, r1 = h2.regions(), h.regions()
+    for k in r1:
+        assert bits_equal(canon(r2[k]), canon(r1[k])), k
+    xyz2, rgba2, idx2 = h2.region_voxels(); xyz1, rgba1, idx1 = h.region_voxels()
+    assert bits_equal(xyz2, xyz1) and np.array_equal(rgba2, rgba1)
+    assert np.array_equal(sv["voxel_leaf"][idx2], idx1)               # input voxel index -> leaf ordinal of the frame
+    # one region id per input voxel = get_labeled_cloud's id of the region that holds it
+    _, lab, _ = h2.voxel_cloud()
+    assert np.array_equal(vlab[idx2], lab)
+
+
+def test_oracle_merge_only_entry_is_invariant_to_keys_and_row_order(oracle, P):
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
+    sv2, pairs2, lut, perm, vox = relabel(sv, pairs, np.random.default_rng(5))
+    rc, region, vlab, res2, h2 = oracle.cluster_supervoxels(sv2, pairs2, prm)
+    assert rc == 0
+    m1 = h.get("MERGES").reshape(-1, 3); m2 = h2.get("MERGES").reshape(-1, 3)
+    assert np.array_equal(m2[:, 2], m1[:, 2]) and np.array_equal(m2[:, :2], map_labels(m1[:, :2], lut))
+    want = h.get("SV_REGION")[np.searchsorted(h.get("SV_LABELS"), sv["label"][perm])]      # row i of sv2 is row perm[i] of sv
+    assert np.array_equal(region, map_labels(want, lut))
+    rc, region1, vlab1, _, _ = oracle.cluster_supervoxels(sv, pairs, prm)
+    assert np.array_equal(vlab, vlab1[vox])
+
+
+def test_oracle_merge_only_entry_error_codes(oracle, P):
+    """Unknown label in a kept adjacency: std::out_of_range from map::at (clustering.cpp:228-229); in a dropped one (first > second): never read
+    (clear_adjacency, :476-486).  Duplicates / self-adjacencies / empty supervoxels: refused (undefined in the reference)."""
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
+    big = int(sv["label"].max()) + 5
+    lo = int(sv["label"].min())
+    assert oracle.cluster_supervoxels(sv, np.vstack([pairs, [[lo, big]]]), prm)[0] == P.ERR_OUT_OF_RANGE
+    assert oracle.cluster_supervoxels(sv, np.vstack([pairs, [[big, lo]]]), prm)[0] == 0
+    kept = pairs[pairs[:, 0] < pairs[:, 1]]
+    assert oracle.cluster_supervoxels(sv, np.vstack([pairs, kept[:1]]), prm)[0] == P.ERR_ARG
+    assert oracle.cluster_supervoxels(sv, np.vstack([pairs, [[lo, lo]]]), prm)[0] == P.ERR_ARG
+    bad = dict(sv); bad["voxel_offset"] = sv["voxel_offset"].copy(); bad["voxel_offset"][1] = bad["voxel_offset"][0]
+    assert oracle.cluster_supervoxels(bad, pairs, prm)[0] == P.ERR_ARG
+    dup = dict(sv); dup["label"] = sv["label"].copy(); dup["label"][1] = dup["label"][0]
+    assert oracle.cluster_supervoxels(dup, pairs, prm)[0] == P.ERR_ARG
+
+
+def test_capi_merge_only_entry_argument_checks_need_no_gpu(P):
+    lib = P.load_library()
+    prm = P.default_params()
+    st = P.SupervoxelSet()
+    assert lib.f3ds_cluster_supervoxels(None, ctypes.byref(st), None, 0, ctypes.byref(prm), None, None, None) == P.ERR_ARG
+    n = ctypes.c_size_t()
+    assert lib.f3ds_get_regions(None, None, None, None, None, None, 0, ctypes.byref(n)) == P.ERR_ARG
+    assert lib.f3ds_get_region_voxels(None, None, None, None, 0, ctypes.byref(n)) == P.ERR_ARG
+    assert b"out of range" in lib.f3ds_strerror(P.ERR_OUT_OF_RANGE)
+    c = P.Clustering()
+    with pytest.raises(TypeError):
+        c.set_initialstate({1: dict(voxels_xyz=np.zeros((1, 3)), voxels_rgba=np.zeros(1), centroid=np.zeros(3), normal=np.zeros(3))})      # adj missing
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the HIP merge loop on the oracle's supervoxels
+def check_against(ctx, h, region, vlab, sv, P):
+    for what in MERGE_ARRAYS:
+        assert first_mismatch(what, ctx.debug(what), h.get(what)) is None
+    assert np.array_equal(region, h.get("SV_REGION")[np.searchsorted(h.get("SV_LABELS"), sv["label"])])
+    for a, b in zip(ctx.voxel_cloud(), h.voxel_cloud()):
+        assert bits_equal(a, b)
+    r, ro = ctx.regions(), h.regions()
+    for k in ro:
+        assert first_mismatch("regions." + k, r[k], ro[k]) is None
+    xyz, rgba, idx = ctx.region_voxels(); oxyz, orgba, oidx = h.region_voxels()
+    assert bits_equal(xyz, oxyz) and np.array_equal(rgba, orgba) and np.array_equal(idx, oidx)
+    _, lab, _ = h.voxel_cloud()
+    assert np.array_equal(vlab[oidx], lab)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES + ["rgbd_160x120_equalization", "rgbd_160x120_rgb_metric", "rgbd_160x120_manual_lambda", "rgbd_320x240_large_supervoxels"])
+def test_gpu_merge_loop_on_the_oracles_supervoxels(oracle, P, gpu_ctx, name):
+    """The oracle's supervoxel map + adjacency multimap of a frame (= what main() passes to set_initialstate) through f3ds_cluster_supervoxels:
+    MERGES, SV_REGION, edges, deltas, weights, regions and the labelled cloud equal the oracle's bit for bit -- against BOTH the oracle's
+    whole-frame run and its merge-only entry; f3ds_recluster continues on the same state."""
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, name)
+    region, vlab = gpu_ctx.cluster_supervoxels(sv, pairs, prm)
+    r = gpu_ctx.result
+    assert (r.n_merges, r.n_regions, r.n_edges, r.n_supervoxels) == (res.n_merges, res.n_regions, res.n_edges, res.n_supervoxels)
+    assert bits_equal(canon(np.float32(r.lambda_)), canon(np.float32(res.lambda_)))
+    rc, oregion, ovlab, ores, h2 = oracle.cluster_supervoxels(sv, pairs, prm)
+    assert rc == 0 and np.array_equal(region, oregion) and np.array_equal(vlab, ovlab)
+    check_against(gpu_ctx, h2, region, vlab, sv, P)
+    for what in MERGE_ARRAYS:                                      # ... and the frame's own clustering
+        assert first_mismatch(what, gpu_ctx.debug(what), h.get(what)) is None
+    kept = pairs[pairs[:, 0] < pairs[:, 1]]
+    assert np.array_equal(gpu_ctx.supervoxel_adjacency(), kept)
+    # cluster(threshold') on the same initial state (clustering.cpp:670-679)
+    p2 = prm.copy(); p2.threshold = 0.35 if prm.merging != P.EQUALIZATION else 0.8
+    vlab2 = gpu_ctx.recluster(p2)
+    rc, _, ores2 = h2.cluster(p2, 0)
+    assert rc == 0 and (gpu_ctx.result.n_merges, gpu_ctx.result.n_regions) == (ores2.n_merges, ores2.n_regions)
+    assert first_mismatch("MERGES", gpu_ctx.debug("MERGES"), h2.get("MERGES")) is None
+    xyz, rgba, idx = h2.region_voxels(); _, lab, _ = h2.voxel_cloud()
+    assert np.array_equal(vlab2[idx], lab)
+    assert np.array_equal(gpu_ctx.region_adjacency(), region_adjacency_of(h2))
+
+
+def region_adjacency_of(h):
+    """weight2adj(state.weight_map) from the oracle's arrays: every initial edge between the labels its endpoints ended in, deduplicated."""
+    labels = h.get("SV_LABELS"); root = h.get("SV_REGION"); e = h.get("EDGES").reshape(-1, 2)
+    lut = dict(zip(labels.tolist(), root.tolist()))
+    out = set()
+    for a, b in e:
+        p, q = lut[int(a)], lut[int(b)]
+        if p != q:
+            out.add((min(p, q), max(p, q)))
+    return np.array(sorted(out), np.uint32).reshape(-1, 2)
+
+
+@pytest.mark.gpu
+def test_gpu_merge_only_entry_sparse_keys_and_permuted_rows(oracle, P, gpu_ctx):
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_320x240_ghosts")
+    sv2, pairs2, lut, perm, vox = relabel(sv, pairs, np.random.default_rng(9))
+    region, vlab = gpu_ctx.cluster_supervoxels(sv2, pairs2, prm)
+    rc, oregion, ovlab, ores, h2 = oracle.cluster_supervoxels(sv2, pairs2, prm)
+    assert rc == 0 and np.array_equal(region, oregion) and np.array_equal(vlab, ovlab)
+    check_against(gpu_ctx, h2, region, vlab, sv2, P)
+    m1 = h.get("MERGES").reshape(-1, 3); m2 = gpu_ctx.debug("MERGES").reshape(-1, 3)
+    assert np.array_equal(m2[:, 2], m1[:, 2]) and np.array_equal(m2[:, :2], map_labels(m1[:, :2], lut))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(F3DS_FORCE_GLOBAL_MERGE="1"), dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="global"), dict(F3DS_MERGE_NW="4", F3DS_MERGE_KEYS="lds"),
+                                 dict(F3DS_MERGE_NW="8", F3DS_MERGE_KEYS="global"), dict(F3DS_MERGE_SPEC="0")])
+def test_gpu_merge_only_entry_in_every_merge_kernel_layout(oracle, P, gpu_ctx, monkeypatch, env):
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    region, vlab = gpu_ctx.cluster_supervoxels(sv, pairs, prm)
+    if "F3DS_FORCE_GLOBAL_MERGE" in env:
+        assert gpu_ctx.merge_layout() == (0, 0)
+    elif "F3DS_MERGE_NW" in env:
+        assert gpu_ctx.merge_layout() == (int(env["F3DS_MERGE_NW"]), 2 if env["F3DS_MERGE_KEYS"] == "lds" else 0)
+    rc, oregion, ovlab, ores, h2 = oracle.cluster_supervoxels(sv, pairs, prm)
+    assert np.array_equal(region, oregion) and np.array_equal(vlab, ovlab)
+    check_against(gpu_ctx, h2, region, vlab, sv, P)
+
+
+@pytest.mark.gpu
+def test_gpu_merge_only_entry_errors_and_state(oracle, P):
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
+    ctx = P.Context(0)
+    big = int(sv["label"].max()) + 5; lo = int(sv["label"].min())
+    with pytest.raises(IndexError):                                     # std::out_of_range (map::at, clustering.cpp:228-229)
+        ctx.cluster_supervoxels(sv, np.vstack([pairs, [[lo, big]]]), prm)
+    with pytest.raises(P.LogicError):                                   # nothing was set: cluster() before set_initialstate (:671-673)
+        ctx.recluster(prm)
+    ctx.cluster_supervoxels(sv, np.vstack([pairs, [[big, lo]]]), prm)   # dropped by clear_adjacency before anything reads it
+    kept = pairs[pairs[:, 0] < pairs[:, 1]]
+    for bad_pairs in (np.vstack([pairs, kept[:1]]), np.vstack([pairs, [[lo, lo]]])):
+        with pytest.raises(P.F3dsError) as e:
+            ctx.cluster_supervoxels(sv, bad_pairs, prm)
+        assert e.value.code == P.ERR_ARG
+    bad = dict(sv); bad["voxel_offset"] = sv["voxel_offset"].copy(); bad["voxel_offset"][1] = bad["voxel_offset"][0]
+    with pytest.raises(P.F3dsError):
+        ctx.cluster_supervoxels(bad, pairs, prm)
+    # no adjacency at all: nothing merges, every supervoxel is its own region
+    region, vlab = ctx.cluster_supervoxels(sv, np.zeros((0, 2), np.uint32), prm)
+    assert np.array_equal(region, sv["label"]) and ctx.result.n_merges == 0 and ctx.result.n_regions == len(sv["label"])
+    assert np.array_equal(vlab, np.repeat(np.arange(len(sv["label"]), dtype=np.uint32), np.diff(sv["voxel_offset"])))
+    # the VCCS-side accessors have nothing to describe
+    for call in (ctx.voxel_centroid_cloud, lambda: ctx.refine_supervoxels(1), lambda: ctx.evaluate(np.zeros(len(vlab), np.uint32))):
+        with pytest.raises(P.LogicError):
+            call()
+    s = ctx.supervoxels()
+    assert np.array_equal(s["label"], sv["label"]) and bits_equal(s["xyz"], sv["centroid_xyz"]) and bits_equal(s["normal"], sv["normal"])
+    assert np.array_equal(s["n_voxels"], np.diff(sv["voxel_offset"]))
+    # an empty map clusters to nothing
+    empty = dict(label=np.zeros(0, np.uint32), voxel_offset=np.zeros(1, np.uint32), voxel_xyz=np.zeros((0, 3), np.float32), voxel_rgba=np.zeros(0, np.uint32),
+                 centroid_xyz=np.zeros((0, 3), np.float32), normal=np.zeros((0, 3), np.float32))
+    region, vlab = ctx.cluster_supervoxels(empty, np.zeros((0, 2), np.uint32), prm)
+    assert len(region) == 0 and len(vlab) == 0 and ctx.result.n_regions == 0
+    # and the context goes back to whole frames
+    assert np.array_equal(ctx.segment(pts, prm), labels)
+    assert len(ctx.voxel_centroid_cloud()[0]) == res.n_voxels
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_python_clustering_mirror_takes_a_supervoxel_map(oracle, P):
+    """Clustering.set_initialstate(segm, adj) in the reference's own shape (a map of supervoxels + an adjacency multimap), get_currentstate() back."""
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
+    segm = {}
+    for i, l in enumerate(sv["label"]):
+        a, b = int(sv["voxel_offset"][i]), int(sv["voxel_offset"][i + 1])
+        segm[int(l)] = dict(voxels_xyz=sv["voxel_xyz"][a:b], voxels_rgba=sv["voxel_rgba"][a:b], centroid=sv["centroid_xyz"][i], normal=sv["normal"][i])
+    c = P.Clustering(P.LAB_CIEDE00, P.CONVEX_NORMALS_DIFF, P.ADAPTIVE_LAMBDA)
+    c.set_initialstate(segm, [tuple(p) for p in pairs.tolist()])
+    c.cluster(0.2)
+    assert bits_equal(np.float32(c.get_lambda()), np.float32(res.lambda_))
+    state, adj = c.get_currentstate()
+    ro = h.regions(); oxyz, orgba, oidx = h.region_voxels()
+    assert list(state.keys()) == ro["label"].tolist()
+    o = 0
+    for k, l in enumerate(ro["label"].tolist()):
+        n = int(ro["n_voxels"][k])
+        assert bits_equal(state[l]["voxels_xyz"], oxyz[o:o + n]) and np.array_equal(state[l]["voxels_rgba"], orgba[o:o + n])
+        assert bits_equal(canon(state[l]["centroid"]), canon(ro["xyz"][k])) and bits_equal(canon(state[l]["normal"]), canon(ro["normal"][k]))
+        o += n
+    assert np.array_equal(adj, region_adjacency_of(h))
+    xyz, lab = c.get_labeled_cloud()
+    oc = h.voxel_cloud()
+    assert bits_equal(xyz, oc[0]) and np.array_equal(lab, oc[1])
+
+
+ADAPTER_SRC = r'''
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <vector>
+#include "f3ds_clustering.hpp"
+template <class T> static std::vector<T> load(const std::string& dir, const char* name) {
+    std::ifstream f(dir + "/" + name, std::ios::binary | std::ios::ate);
+    if (!f) { std::fprintf(stderr, "missing %s\n", name); std::exit(90); }
+    const size_t nb = (size_t)f.tellg(); f.seekg(0);
+    std::vector<T> v(nb / sizeof(T)); if (nb) f.read((char*)v.data(), nb); return v;
+}
+static bool same(const float* a, const float* b, size_t n) { for (size_t i = 0; i < n; ++i) if (!(a[i] == b[i] || (a[i] != a[i] && b[i] != b[i]))) return false; return true; }
+int main(int argc, char** argv) {
+    const std::string dir = argv[1];
+    if (f3ds_device_count() < 1) return 77;
+    // ---- (1) the frame through SupervoxelClustering + Clustering: per-point labels of the ORACLE
+    auto pts = load<f3ds::PointXYZRGBA>(dir, "points.bin");
+    auto want_labels = load<uint32_t>(dir, "labels.bin");
+    f3ds::SupervoxelClustering super(0.02f, 0.2f);
+    super.setInputCloud(pts.data(), pts.size());
+    f3ds::Supervoxels sv = super.extract();
+    f3ds::Clustering seg(f3ds::LAB_CIEDE00, f3ds::CONVEX_NORMALS_DIFF, f3ds::ADAPTIVE_LAMBDA);
+    seg.set_initialstate(super);
+    seg.cluster(0.2f);
+    if (seg.get_point_labels() != want_labels) return 23;
+    // ---- (2) set_initialstate(segm, adj) with the ORACLE's supervoxel map and adjacency multimap (clustering.h:142), cluster, get_currentstate
+    auto label = load<uint32_t>(dir, "sv_label.bin"); auto off = load<uint32_t>(dir, "sv_offset.bin"); auto xyz = load<float>(dir, "sv_xyz.bin");
+    auto rgba = load<uint32_t>(dir, "sv_rgba.bin"); auto cen = load<float>(dir, "sv_centroid.bin"); auto nrm = load<float>(dir, "sv_normal.bin");
+    auto pairs = load<uint32_t>(dir, "pairs.bin");
+    f3ds::ClusteringT segm; f3ds::AdjacencyMapT adj;
+    for (size_t i = 0; i < label.size(); ++i) {
+        f3ds::Supervoxel s;
+        for (uint32_t v = off[i]; v < off[i + 1]; ++v) s.voxels.push_back(f3ds::PointXYZRGBA{xyz[3 * v], xyz[3 * v + 1], xyz[3 * v + 2], rgba[v]});
+        for (int a = 0; a < 3; ++a) { s.centroid[a] = cen[3 * i + a]; s.normal[a] = nrm[3 * i + a]; }
+        segm[label[i]] = s;
+    }
+    for (size_t k = 0; k + 1 < pairs.size(); k += 2) adj.insert({pairs[k], pairs[k + 1]});
+    f3ds::Clustering c2(f3ds::LAB_CIEDE00, f3ds::CONVEX_NORMALS_DIFF, f3ds::ADAPTIVE_LAMBDA);
+    c2.set_initialstate(segm, adj);
+    c2.cluster(0.2f);
+    auto want_region = load<uint32_t>(dir, "sv_region.bin");              // oracle: SV_REGION (ascending label)
+    if (c2.get_region_of_supervoxel() != want_region) return 30;
+    auto st = c2.get_currentstate();
+    auto r_label = load<uint32_t>(dir, "r_label.bin"); auto r_cnt = load<uint32_t>(dir, "r_count.bin"); auto r_cen = load<float>(dir, "r_centroid.bin");
+    auto r_nrm = load<float>(dir, "r_normal.bin"); auto r_xyz = load<float>(dir, "r_xyz.bin"); auto r_adj = load<uint32_t>(dir, "r_adj.bin");
+    if (st.first.size() != r_label.size()) return 31;
+    size_t i = 0, o = 0;
+    for (const auto& kv : st.first) {
+        if (kv.first != r_label[i] || kv.second.voxels.size() != r_cnt[i]) return 32;
+        if (!same(kv.second.centroid, &r_cen[3 * i], 3) || !same(kv.second.normal, &r_nrm[3 * i], 3)) return 33;
+        for (const auto& p : kv.second.voxels) { const float q[3] = {p.x, p.y, p.z}; if (!same(q, &r_xyz[3 * o], 3)) return 34; ++o; }
+        ++i;
+    }
+    if (st.second.size() * 2 != r_adj.size()) return 35;
+    i = 0;
+    for (const auto& kv : st.second) { if (kv.first != r_adj[2 * i] || kv.second != r_adj[2 * i + 1]) return 36; ++i; }
+    // a second threshold continues from the same initial state (cluster() again, :670-679)
+    c2.cluster(0.0f);
+    if (c2.get_currentstate().first.size() != label.size()) return 37;
+    // ---- (3) the reference's exceptions on this path
+    f3ds::AdjacencyMapT bad = adj; bad.insert({label[0], 0xFFFFFFF0u});
+    f3ds::Clustering c3;
+    c3.set_initialstate(segm, bad);
+    try { c3.cluster(0.2f); return 40; } catch (const std::out_of_range&) {}             // map::at, clustering.cpp:228-229
+    std::vector<uint32_t> truth(pts.size(), 0u);
+    try { seg.all_thresh(truth.data(), -0.5f, 0.5f, 0.1f); return 41; } catch (const std::out_of_range&) {}      // :694-698
+    std::puts("adapter ok");
+    return 0;
+}
+'''
+
+
+@pytest.mark.gpu
+def test_gpu_cpp_clustering_adapter_against_the_oracle(oracle, P, tmp_path):
+    """The gpu-marked twin of test_capi.py::test_cpp_clustering_adapter: include/f3ds_clustering.hpp (the C++ mirror of class Clustering) run on a GPU
+    and compared with the ORACLE -- per-point labels of the frame, and set_initialstate(segm, adj) / get_currentstate() on the oracle's supervoxels."""
+    pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
+    d = tmp_path
+    def dump(name, a):
+        np.ascontiguousarray(a).tofile(str(d / name))
+    dump("points.bin", pts); dump("labels.bin", labels)
+    dump("sv_label.bin", sv["label"]); dump("sv_offset.bin", sv["voxel_offset"]); dump("sv_xyz.bin", sv["voxel_xyz"]); dump("sv_rgba.bin", sv["voxel_rgba"])
+    dump("sv_centroid.bin", sv["centroid_xyz"]); dump("sv_normal.bin", sv["normal"]); dump("pairs.bin", pairs)
+    dump("sv_region.bin", h.get("SV_REGION"))
+    ro = h.regions(); oxyz, orgba, oidx = h.region_voxels()
+    dump("r_label.bin", ro["label"]); dump("r_count.bin", ro["n_voxels"]); dump("r_centroid.bin", ro["xyz"]); dump("r_normal.bin", ro["normal"]); dump("r_xyz.bin", oxyz)
+    dump("r_adj.bin", region_adjacency_of(h))
+    src = d / "adapter_gpu.cpp"
+    src.write_text(ADAPTER_SRC)
+    pkg_dir = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd")
+    exe = d / "adapter_gpu"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), "-L", pkg_dir, "-lf3ds", "-Wl,-rpath," + pkg_dir], check=True)
+    r = subprocess.run([str(exe), str(d)], capture_output=True, text=True)
+    assert r.returncode == 0 and "adapter ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_cpp_adapter_with_a_supervoxel_map_compiles_without_a_gpu(tmp_path):
+    """The adapter program of the GPU test builds on the CPU box too (header-only over the C-ABI): the interface cannot rot unnoticed between GPU runs."""
+    src = tmp_path / "adapter_gpu.cpp"
+    src.write_text(ADAPTER_SRC)
+    pkg_dir = os.path.join(ROOT, "fast-3d-pointcloud-segmentation_amd")
+    subprocess.run(["g++", "-O0", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)], check=True)

@@ -217,3 +217,68 @@ def test_bench_spawns_the_ranks_itself(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and "127.0.0.1" in cmd
     assert "torch" not in bench.__dict__        # the parent never imported torch at module level
+
+
+def test_bench_cpu_baseline_is_voided_when_the_libm_oracle_disagrees():
+    """bench.py: the CPU baseline is timed on the libm-linked oracle; if its labels differ from the shared-math build's (the parity checker) the
+    baseline is void -- value null, reason stated -- instead of the TypeError the round-4 code raised at that point (`cpu` was still None)."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    ok = bench.cpu_baseline_record(1000000, 2.5, 4.0, 5.0, True, 8)
+    assert ok["value"] == 0.4 and ok["cores"] == 1 and ok["kind"] == "port" and "invalid" not in ok and ok["as_main_runs_it"]["value"] == 0.2
+    bad = bench.cpu_baseline_record(1000000, 2.5, 4.0, 5.0, False, 8)
+    assert bad["value"] is None and bad["as_main_runs_it"]["value"] is None and "differ" in bad["invalid"] and bad["labels_equal_shared_math_build"] is False
+    est = bench.strong_estimate({"one_batch_of_64_frames_one_gpu": 56.0, "one_call_of_8_frames": 39.2}, 1000000)
+    assert est["n8_ms_estimated"] == 39.2 and est["speedup_8_gpus_estimated"] == 1.43 and "UNMEASURED" in est["what"]
+    assert bench.strong_estimate(None, 1000000) is None
+
+
+def _strong_worker(rank, world, port, n_steps, q):
+    """bench.py --strong on CPU tensors: ONE batch of 8 frames per step for the whole job, frame i on rank i mod N; every rank runs its 8 / N frames through
+    the step pipeline and the step's label blocks go to rank 0 in one gather, where block r row k is global frame k * N + r of that step."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    B = importlib.import_module("fast-3d-pointcloud-segmentation_amd.batch")
+    GLOBAL, NP, NB = 8, 40, 4
+    mine = B.frames_of_rank(GLOBAL, rank, world)
+    FPS = len(mine)
+    blocks = [torch.zeros((FPS, NP), dtype=torch.int32) for _ in range(NB)]
+    bufs = [torch.empty((FPS, NP), dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    seen, pipe_ref = [], []
+
+    def run_batch(g, f0, f1):
+        for f in range(f0, f1):                       # local frame f = step f // FPS, slot f % FPS = global frame mine[slot] of that step
+            blk, slot = pipe_ref[0].block_of(f)
+            blocks[blk][slot].fill_((f // FPS) * 1000 + mine[slot])
+
+    def on_step(s):
+        got = B.gather_label_block(blocks[s % NB], dist, bufs, dst=0)
+        if rank == 0:
+            seen.append(B.assemble_strong([g.clone() for g in got]))
+
+    pipe = B.StepPipeline(FPS, 6, 2, NB, run_batch, on_step)
+    pipe_ref.append(pipe)
+    pipe.run(n_steps)
+    if rank == 0:
+        ok = len(seen) == n_steps
+        for s in range(n_steps):
+            ok &= [int(seen[s][i, 0]) for i in range(GLOBAL)] == [s * 1000 + i for i in range(GLOBAL)]
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_strong_scaling_shards_one_batch_and_gathers_it_in_frame_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True

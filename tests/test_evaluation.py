@@ -164,7 +164,7 @@ def test_oracle_auto_threshold(P, oracle):
         h.cluster(p2, len(pts))
         assert h.evaluate(truth)[1].as_dict() == table[t]
     # argument rules of all_thresh (clustering.cpp:693-705): out of range -> invalid_argument, swapped bounds accepted
-    assert h.auto_threshold(prm, truth, len(pts), -0.1, 0.5, 0.1)[0] == P.ERR_RANGE
-    assert h.auto_threshold(prm, truth, len(pts), 0.1, 1.5, 0.1)[0] == P.ERR_RANGE
+    assert h.auto_threshold(prm, truth, len(pts), -0.1, 0.5, 0.1)[0] == P.ERR_OUT_OF_RANGE      # std::out_of_range, clustering.cpp:694-698
+    assert h.auto_threshold(prm, truth, len(pts), 0.1, 1.5, 0.1)[0] == P.ERR_OUT_OF_RANGE
     rc, _, _, swapped, _ = h.auto_threshold(prm, truth, len(pts), 0.6, 0.05, 0.05)
     assert rc == 0 and swapped == table

@@ -255,9 +255,9 @@ def test_auto_threshold_matches_oracle(P, oracle, gpu_ctx):
         assert rc == 0 and bt == obt and bp.as_dict() == obp.as_dict() and table == otable and np.array_equal(labels, olabels)
         assert gpu_ctx.result.n_regions == len(np.unique(olabels[olabels != 0xFFFFFFFF]))
         assert gpu_ctx.evaluate(truth).as_dict() == bp.as_dict() or bt == 0.0
-    with pytest.raises(ValueError):
+    with pytest.raises(IndexError):                 # std::out_of_range, clustering.cpp:694-698
         gpu_ctx.auto_threshold(prm, truth, -0.5, 0.5, 0.1)
-    with pytest.raises(ValueError):
+    with pytest.raises(IndexError):
         gpu_ctx.auto_threshold(prm, truth, 0.1, 0.5, 0.0)
     with pytest.raises(P.LogicError):
         P.Context(0).evaluate(np.zeros(0, np.uint32))
@@ -325,6 +325,40 @@ def test_dirty_tile_sweeps_are_bit_identical_at_any_setting(P, shift):
         assert got[n]["labels"] == gold[n]["labels_sha256"], (n, shift)
         for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
             assert got[n][w] == gold[n]["sha256"][w], (n, w, shift)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rounds", ["1", "2"])
+def test_incremental_R_rounds_that_do_not_converge_fall_back_to_the_chain_walker(P, rounds):
+    """An incremental sweep whose last R round still changes ownR turns full (d_sweep_R_round); no pre-pass has run for it, so pass 0 of the chain
+    walker derives R for every voxel itself (d_sweep_R, `sweep_pre`).  Until round 5 that fallback did nothing -- the walker found an empty work list
+    and the claim pass ran on a half-converged ownR -- and no test reached it: three rounds settle every frame seen so far.  F3DS_R_ROUNDS_RUN=1 makes
+    round 0 the last one (any change at all falls back), F3DS_INC_SHIFT=32 makes every sweep from the third on incremental."""
+    import json, subprocess, sys
+    names = ["rgbd_320x240_ghosts", "rgbd_320x240_large_supervoxels", "fixture_launch_flags", "rgbd_160x120"]
+    code = (
+        "import sys, json, hashlib; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import conftest; from golden_cases import case_points, case_params\n"
+        "P = conftest.pkg(); ctx = P.Context(0); out = {}\n"
+        "for n in %r:\n"
+        "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
+        "    out[n] = dict(labels=conftest.sha_of(lab), **{w: conftest.sha_of(ctx.debug(w)) for w in ('VOXEL_SVLABEL', 'VOXEL_DIST', 'SV_CENTROID', 'MERGES')})\n"
+        "    r = ctx.refine_supervoxels(2); out[n]['refined'] = conftest.sha_of(r['voxel_label'])\n"
+        "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
+    got = {}
+    for env_rounds in (rounds, None):
+        env = dict(os.environ, F3DS_INC_SHIFT="32")
+        if env_rounds:
+            env["F3DS_R_ROUNDS_RUN"] = env_rounds
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[env_rounds] = json.loads(r.stdout.strip().splitlines()[-1])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
+    for n in names:
+        assert got[rounds][n]["labels"] == gold[n]["labels_sha256"], (n, rounds)
+        for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
+            assert got[rounds][n][w] == gold[n]["sha256"][w], (n, w, rounds)
+        assert got[rounds][n]["refined"] == got[None][n]["refined"], (n, "refineSupervoxels")
 
 
 MERGE_VARIANTS = ([dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("4", "8") for k in ("lds", "global")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")] +
@@ -1073,9 +1107,28 @@ def test_bench_distributed_bookkeeping_with_one_forced_rank(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["unit"] == "Mpoints/s" and line["scaling"] == "weak"
     assert "RCCL gather" in line["config"]["label_gather"] and line["config"]["frames_timed"] == 128
-    assert line["roofline"]["kernel"].startswith("k_batched<d_merge") and line["library"].startswith("f3ds 1.1.0 src:")
+    assert line["roofline"]["kernel"].startswith("k_batched<d_merge") and line["library"].startswith("f3ds 1.2.0 src:")
     # 160x120 frames are not BASELINE's workload: the line carries no `value`, the rate sits under what_if_value
     assert line["value"] is None and "not the BASELINE workload" in line["invalid"] and line["what_if_value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_strong_mode_with_one_forced_rank(tmp_path):
+    """bench.py --strong: BASELINE config 5 as written (ONE 64-frame batch per step for the whole job, frame i on rank i mod N, one gather per step), through
+    the N > 1 branch with one forced rank.  N = 1 shards nothing, so this checks the bookkeeping (scaling field, seeds, label hashes at full size are the
+    weak mode's); the two-rank sharding and reassembly run on gloo in tests/test_distributed_cpu.py.  UNMEASURED on N > 1 hardware."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, F3DS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--strong", "--steps", "2", "--warmup", "1", "--batch", "64", "--groups", "2", "--width", "160",
+                        "--height", "120", "--host-io-steps", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode in (0, 1), r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["frames_timed"] == 128 and line["config"]["frames_per_step_per_gpu"] == 64
+    assert "ONE batch of 64" in line["config"]["workload"] and "RCCL gather" in line["config"]["label_gather"]
+    est = line["strong_scaling_estimate"]
+    assert est and est["n8_ms_estimated"] > 0 and "UNMEASURED" in est["what"]
 
 
 @pytest.mark.gpu
