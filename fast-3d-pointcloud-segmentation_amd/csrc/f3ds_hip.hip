@@ -107,7 +107,7 @@ const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e 
 // call of the library (f3ds_segment_batch, f3ds_recluster, f3ds_refine_supervoxels) into this per-thread struct -- not per frame on the hot path,
 // where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
 struct Switches {
-    bool direct_labels = false, copy_stream = true, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false;
+    bool direct_labels = false, copy_stream = true, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false, vox_hash = true, vox_tiles_forced = false;
     int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32, r_rounds = F3DS_R_ROUNDS; long relabel_lds_cap = -1;
     void read() {
         auto on = [](const char* n) { return getenv(n) != nullptr; };
@@ -115,6 +115,8 @@ struct Switches {
         direct_labels = num("F3DS_DIRECT_LABELS", 0) != 0; copy_stream = num("F3DS_COPY_STREAM", 1) != 0; split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
         force_global_merge = on("F3DS_FORCE_GLOBAL_MERGE"); no_stream_pool = on("F3DS_NO_STREAM_POOL"); sort_pairs = on("F3DS_SORT_PAIRS");
         host_prof = on("F3DS_HOST_PROF"); trace_err = on("F3DS_TRACE_ERR");
+        vox_tiles_forced = num("F3DS_VOX_TILES", 1) == 2;      // (2: also for lone frames -- tests)
+        vox_hash = num("F3DS_VOX_TILES", 1) != 0 && !sort_pairs && !split_voxel_accum;      // (0: stage 0 by sorting the points, as until round 4; the two development switches of that path imply it)
         normals_threads = (int)num("F3DS_NORMALS_THREADS", 0); tile_holes = (uint32_t)num("F3DS_SWEEP_TILE_HOLES", 0);
         { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 4 ? 4 : (v ? 8 : 0); }
         { const char* e = getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
@@ -166,6 +168,9 @@ struct f3ds_ctx {
     int merge_kind = 0;                // which merge kernel the last cluster stage ran (MergeKind)
     uint32_t ev_mult = 64;             // weight-history events per initial edge the merge loop may write
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
+    uint32_t vox_cap = 0;              // bound on the leaves of the current frame that stage 0's tile path sized its buffers by
+    bool vox_hashed = false;           // stage 0 of the current frame took the tile path (seg_vox_tiles)
+    bool vox_dense = false;            // this context met a frame the tile path refuses (an unorganised cloud, a voxel of more than VL_MAX_RUN points): its frames take the sort path
     uint32_t ilist_mult = 1;           // incident-list pool size factor (its own: a leaf-pool overflow must not grow the list pool too)
     uint32_t edge_mult = 32;           // adjacency list room per seed (S0 * edge_mult + 1024), grown on demand
     bool relabel_lds = true;           // stage 6 as one kernel (the region-id table fits LDS for every frame of the batch)
@@ -181,6 +186,7 @@ struct f3ds_ctx {
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
     Buf tstamp, tround, hdirty, htiles, htcnt, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
+    Buf hcnt, pslot, vlist;      // stage 0, tile path: per (tile, entry) point count / list base / leaf ordinal; per point its (entry, rank in tile); per-leaf point lists
     Buf u_src, u_voff, u_xyz, u_rgba, u_cent, u_nrm;      // f3ds_cluster_supervoxels: the caller's supervoxels as uploaded
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, ilist, istart, ilen, icap, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
     std::vector<uint32_t> tsize;       // voxels per truth label (evaluation)
@@ -443,7 +449,8 @@ int scan_u32(f3ds_ctx* c, const uint32_t* in, uint32_t* out, uint32_t n) {
     return F3DS_OK;
 }
 // stable sort of (key,val) pairs on the low `total_bits` bits (the same for every frame of a batch)
-int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint32_t n, int total_bits, uint64_t** keys_out, uint32_t** vals_out, int base_shift = 0) {
+// (n_dev: the element count lives on the device and `n` only bounds it -- pair sorts only)
+int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* v1, uint32_t n, int total_bits, uint64_t** keys_out, uint32_t** vals_out, int base_shift = 0, const uint32_t* n_dev = nullptr) {
     *keys_out = k0; if (vals_out) *vals_out = v0;
     if (total_bits <= 0) return F3DS_OK;
     const int passes = (total_bits + RS_MAXBITS - 1) / RS_MAXBITS;
@@ -454,9 +461,9 @@ int radix_sort(f3ds_ctx* c, uint64_t* k0, uint32_t* v0, uint64_t* k1, uint32_t* 
     int shift = 0;
     for (int p = 0; p < passes; ++p) {
         const int bits = (total_bits - shift) < per ? (total_bits - shift) : per;
-        rec<d_radix_hist>(c, nb, 0u, (const uint64_t*)k0, n, base_shift + shift, bits, hist, nb);
+        rec<d_radix_hist>(c, nb, 0u, (const uint64_t*)k0, n, base_shift + shift, bits, hist, nb, n_dev);
         rec<d_scan_single>(c, 1u, 0u, hist, (uint32_t)((1u << bits) * nb));
-        if (v0) rec<d_radix_scatter>(c, nb, 0u, (const uint64_t*)k0, (const uint32_t*)v0, k1, v1, n, base_shift + shift, bits, (const uint32_t*)hist, nb);
+        if (v0) rec<d_radix_scatter>(c, nb, 0u, (const uint64_t*)k0, (const uint32_t*)v0, k1, v1, n, base_shift + shift, bits, (const uint32_t*)hist, nb, n_dev);
         else rec<d_radix_scatter_k>(c, nb, 0u, (const uint64_t*)k0, k1, n, base_shift + shift, bits, (const uint32_t*)hist, nb);      // payload in the key's low bits
         std::swap(k0, k1); std::swap(v0, v1);
         shift += bits;
@@ -501,10 +508,48 @@ int seg_sort(f3ds_ctx* c, int sort_bits, int idxbits) {      // idxbits >= 0: (c
     rec<d_seg_write>(c, nt, 0u, (const uint64_t*)c->ks, n, invalid, ks, (const uint32_t*)tiles, seg_start, &c->d_dc->n_voxels, &c->d_dc->n_valid);
     return F3DS_OK;
 }
+// stage 0b + 0c without sorting the points (f3ds_kernels.inc, "stage 0 without sorting the points"): per-tile LDS grouping, sort of the tiles' descriptors, per-leaf
+// point lists, ordered leaf sums.  Everything is recorded before V is known: buffers and grids are sized by bounds, the kernels read the counts from the device.
+int seg_vox_tiles(f3ds_ctx* c, int code_bits, int tile_bits) {      // (code_bits, tile_bits: the same for every frame of a batch -- the frames record the same sort passes)
+    const uint32_t n = c->n;
+    const uint32_t ntiles = (n + VT_TILE - 1u) / VT_TILE;
+    const uint64_t dcap64 = (uint64_t)ntiles * VT_ENT_MAX;
+    if (code_bits + tile_bits > 64 || dcap64 > 0x7fffffffull || (uint64_t)ntiles * VT_TAB > 0x7fffffffull) return F3DS_ERR_UNSUPPORTED;      // (the caller takes the sort path)
+    const uint32_t dcap = (uint32_t)dcap64;
+    const uint64_t fin = c->h_dc->n_finite;
+    const uint32_t capV = (uint32_t)std::max<uint64_t>(256u, std::min<uint64_t>(fin, dcap));
+    c->vox_cap = capV;
+    uint64_t *k0, *k1; uint32_t *ploc, *v0, *v1, *cnt_te, *base_te, *ord_te, *vkey, *vcount, *seg_start, *list; float* vf; int* pt_voxel;
+    ENSURE(c->pslot, uint32_t, n, ploc); ENSURE(c->keys0, uint64_t, dcap, k0); ENSURE(c->keys1, uint64_t, dcap, k1); ENSURE(c->vals0, uint32_t, dcap, v0); ENSURE(c->vals1, uint32_t, dcap, v1);
+    ENSURE(c->hcnt, uint32_t, (size_t)ntiles * VT_TAB * 3, cnt_te); base_te = cnt_te + (size_t)ntiles * VT_TAB; ord_te = base_te + (size_t)ntiles * VT_TAB;
+    ENSURE(c->vkey, uint32_t, (size_t)capV * 3, vkey); ENSURE(c->vcount, uint32_t, capV, vcount); ENSURE(c->vf, float, (size_t)capV * 12, vf);
+    ENSURE(c->seg_start, uint32_t, (size_t)capV + 1, seg_start); ENSURE(c->vlist, uint32_t, n, list); ENSURE(c->pt_voxel, int, n, pt_voxel);
+    { uint32_t *f, *incl; ENSURE(c->flags, uint32_t, capV, f); ENSURE(c->incl, uint32_t, capV, incl); }      // (the seed stage scans V / C flags through them without asking)
+    c->idxbits = -1; c->ks = nullptr; c->vs = nullptr;
+    rec<d_tile_keys>(c, std::min<uint32_t>(ntiles, (uint32_t)g_grid_cap * 8u), 0u, c->d_pts, n, c->fa, (const GridInfo*)c->d_grid, ploc, k0, v0, cnt_te, dcap, tile_bits, c->d_dc);
+    uint64_t* ks; uint32_t* vs;
+    int rc = radix_sort(c, k0, v0, k1, v1, dcap, code_bits + tile_bits, &ks, &vs, 0, &c->d_dc->seg_count);
+    if (rc) return rc;
+    rec<d_desc_scan>(c, 1u, 0u, (const uint64_t*)ks, (const uint32_t*)vs, (const uint32_t*)cnt_te, dcap, capV, tile_bits, c->fa, (const GridInfo*)c->d_grid, base_te, ord_te, seg_start, vkey, c->d_dc);
+    rec<d_tile_place>(c, std::min<uint32_t>(grid_wide(n, 1024), (uint32_t)g_grid_cap * 4u), 0u, (const uint32_t*)ploc, n, (const uint32_t*)base_te, (const uint32_t*)ord_te, list, pt_voxel, (const DevCounters*)c->d_dc);
+    rec<d_voxel_list_accum>(c, std::min<uint32_t>(grid_wide(capV, 256), std::max<uint32_t>(64u, grid_wide(n / 8u, 256))), 0u, c->d_pts, list, (const uint32_t*)seg_start, c->fa, vf, vcount, c->d_dc, capV);
+    c->vox_hashed = true;
+    return F3DS_OK;
+}
 // stage 0c + 1 + 2a: voxel sums, neighbour tables, normals, seed grid growth
 int seg_voxels(f3ds_ctx* c) {
     const uint32_t V = c->V, n = c->n;
     uint32_t *vkey, *vcount, *hvals; float *vf; int *nbr, *nbrT; uint64_t* hkeys;
+    if (c->vox_hashed) {      // the leaf sums exist already (seg_vox_tiles): the leaf keys go into the hash table, then the neighbour search
+        const uint32_t hc2 = pow2_ge((size_t)V * 2 + 16);
+        c->hmask = hc2 - 1;
+        ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hc2, hkeys); ENSURE(c->hvals, uint32_t, hc2, hvals);
+        rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hc2 * 8);
+        rec<d_vox_hash>(c, 1u, 0u, (const uint32_t*)c->vkey.p, V, hkeys, hvals, c->hmask);
+        rec<d_neighbors>(c, grid_wide((size_t)V * 27, 256), 0u, (const uint32_t*)c->vkey.p, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
+                         c->hmask, nbr, nbrT);
+        return F3DS_OK;
+    }
     const uint32_t hcap = pow2_ge((size_t)V * 2 + 16);
     c->hmask = hcap - 1;
     ENSURE(c->vkey, uint32_t, (size_t)V * 3, vkey); ENSURE(c->vcount, uint32_t, V, vcount); ENSURE(c->vf, float, (size_t)V * 12, vf);
@@ -1132,13 +1177,43 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     if ((rc = drop_dead([](f3ds_ctx* c) { return c->h_dc->grid_empty || c->n == 0; }))) return rc;
     int maxd = 0;
     for (f3ds_ctx* c : b.fr) if (c->h_dc->depth > maxd) maxd = c->h_dc->depth;
-    // (Morton code << idxbits) | point index in one 64-bit word when both fit: the sort then moves 8 bytes per point and pass, not 12
-    uint32_t maxn = 1;
-    for (f3ds_ctx* c : b.fr) if (c->n > maxn) maxn = c->n;
-    int idxbits = bits_for((uint64_t)maxn - 1u);
-    if (3 * maxd + 1 + idxbits > 64 || g_sw.sort_pairs) idxbits = -1;
-    if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_sort(c, 3 * maxd + 1, idxbits); })) || (rc = flush_sync(b))) return rc;
-    for (f3ds_ctx* c : b.fr) { c->V = c->h_dc->n_voxels; c->res.n_voxels = c->V; }
+    // Stage 0b/0c.  Default: the hash path (only the voxels are sorted).  The sort path (every point's key through a three-pass radix sort) remains for frames with
+    // very dense voxels and behind F3DS_VOX_HASH=0.
+    // (a lone frame takes the sort path: two of the tile path's kernels are one workgroup per frame -- 2.4 ms on a lone frame's critical path, nothing in a batch)
+    bool hashed = g_sw.vox_hash && (nctx >= 4 || g_sw.vox_tiles_forced);
+    for (f3ds_ctx* c : b.fr) { c->vox_hashed = false; if (c->vox_dense) hashed = false; }
+    if (hashed) {
+        uint32_t maxtiles = 1;
+        for (f3ds_ctx* c : b.fr) maxtiles = std::max(maxtiles, (c->n + VT_TILE - 1u) / VT_TILE);
+        const int tile_bits = bits_for((uint64_t)maxtiles - 1u);
+        rc = for_frames(b, [&](f3ds_ctx* c) { return seg_vox_tiles(c, 3 * maxd, tile_bits); });
+        if (rc == F3DS_ERR_UNSUPPORTED) {      // (a grid too deep / a frame too long for this path: nothing was flushed)
+            for (f3ds_ctx* c : b.fr) { c->cmds.clear(); c->blob.clear(); c->pend.clear(); c->ops.n = 0; c->ops_grid = 0; c->vox_hashed = false; }
+            hashed = false;
+        } else if (rc || (rc = flush_sync(b))) return rc;
+        if (hashed && g_sw.trace_err) for (f3ds_ctx* c : b.fr) fprintf(stderr, "f3ds: tile path: most voxels in a tile %u, descriptors %u, leaves %u, lists sorted %u\n", c->h_dc->vox_max_tile, c->h_dc->seg_count, c->h_dc->n_voxels, c->h_dc->vox_disorder);
+        if (hashed) for (f3ds_ctx* c : b.fr) if (c->h_dc->ev_overflow == 6 || c->h_dc->ev_overflow == 7) {
+            if (g_sw.trace_err) fprintf(stderr, "f3ds: tile path refused a frame: %s (descriptors %u, leaves %u)\n", c->h_dc->ev_overflow == 6 ? "a voxel with too many points" : "a tile with too many voxels", c->h_dc->seg_count, c->h_dc->n_voxels);
+            c->vox_dense = true; hashed = false;
+        }
+        if (!hashed) {
+            if (g_sw.trace_err) fprintf(stderr, "f3ds: voxelisation of %zu frames runs again on the sort path (an unorganised cloud or dense voxels)\n", b.fr.size());
+            for (f3ds_ctx* c : b.fr) {
+                c->h_dc->error = 0; c->h_dc->ev_overflow = 0; c->vox_hashed = false;
+                HIPCHECK(hipMemsetAsync(&c->d_dc->error, 0, sizeof(int), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->ev_overflow, 0, sizeof(int), b.st));
+                HIPCHECK(hipMemsetAsync(&c->d_dc->n_voxels, 0, sizeof(uint32_t), b.st)); HIPCHECK(hipMemsetAsync(&c->d_dc->seg_count, 0, sizeof(uint32_t), b.st));
+            }
+        }
+    }
+    if (!hashed) {
+        // (Morton code << idxbits) | point index in one 64-bit word when both fit: the sort then moves 8 bytes per point and pass, not 12
+        uint32_t maxn = 1;
+        for (f3ds_ctx* c : b.fr) if (c->n > maxn) maxn = c->n;
+        int idxbits = bits_for((uint64_t)maxn - 1u);
+        if (3 * maxd + 1 + idxbits > 64 || g_sw.sort_pairs) idxbits = -1;
+        if ((rc = for_frames(b, [&](f3ds_ctx* c) { return seg_sort(c, 3 * maxd + 1, idxbits); })) || (rc = flush_sync(b))) return rc;
+    }
+    for (f3ds_ctx* c : b.fr) { if (c->h_dc->error) return trace_err(c->h_dc->error, "voxelisation", c); c->V = c->h_dc->n_voxels; c->res.n_voxels = c->V; }
     if ((rc = drop_dead([](f3ds_ctx* c) { return c->V == 0; }))) return rc;
     stage_mark(b, 1);
     // ---- stage 1 + 2: neighbours, normals, seeds

@@ -27,7 +27,9 @@ def _invariants(P, pts, labels, res):
     assert res.n_voxels <= res.n_finite and res.n_seeds <= res.n_seed_cells
 
 
-def test_1m_frame_matches_oracle(P, oracle, gpu_ctx):
+@pytest.mark.parametrize("stage0", ["sort", "tiles"])
+def test_1m_frame_matches_oracle(P, oracle, gpu_ctx, stage0, monkeypatch):
+    monkeypatch.setenv("F3DS_VOX_TILES", "2" if stage0 == "tiles" else "0")       # stage 0 by sorting the points (a lone frame's path) | by tiles (the frames of a batch)
     pts = P.synth_frame(0, 1000, 1000, 1000, 30)
     prm = P.launch_params()
     labels = gpu_ctx.segment(pts, prm)
@@ -43,7 +45,9 @@ def test_1m_frame_matches_oracle(P, oracle, gpu_ctx):
     assert np.array_equal(labels, again)
 
 
-def test_nyu_scale_frame_matches_oracle(P, oracle, gpu_ctx):
+@pytest.mark.parametrize("stage0", ["sort", "tiles"])
+def test_nyu_scale_frame_matches_oracle(P, oracle, gpu_ctx, stage0, monkeypatch):
+    monkeypatch.setenv("F3DS_VOX_TILES", "2" if stage0 == "tiles" else "0")
     pts = P.synth_frame(0, 2000, 640, 480, 200)
     prm = P.launch_params()
     labels = gpu_ctx.segment(pts, prm)

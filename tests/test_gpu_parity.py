@@ -15,8 +15,12 @@ pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_golden.json")))
 
 
+@pytest.mark.parametrize("stage0", ["sort", "tiles"])
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
-def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name):
+def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name, stage0, monkeypatch):
+    """Every intermediate array of every golden case, with stage 0 (voxelisation) on either of its paths: the three-pass radix sort of all points (what a lone frame
+    takes) and the tile path (per-tile grouping in LDS + a sort of the tiles' voxel descriptors: what the frames of a batch take; F3DS_VOX_TILES=2 forces it here)."""
+    monkeypatch.setenv("F3DS_VOX_TILES", "2" if stage0 == "tiles" else "0")
     pts = case_points(P, name)
     prm = case_params(P, name)
     rc, olab, ores, oh = oracle.segment(pts, prm)
@@ -40,6 +44,39 @@ def test_every_stage_matches_oracle_and_golden(P, oracle, gpu_ctx, name):
     ox, ol, oc = oh.voxel_cloud()
     gx, gl, gc = gpu_ctx.voxel_cloud()
     assert np.array_equal(ox.view(np.uint32), gx.view(np.uint32)) and np.array_equal(ol, gl) and np.array_equal(oc, gc)
+
+
+def test_tile_voxelisation_falls_back_where_it_must_and_agrees_everywhere(P, oracle, monkeypatch):
+    """Stage 0's tile path refuses, per context and for good, what it is not made for -- an unorganised cloud (no locality: a tile holds more distinct voxels than its
+    LDS table), voxels of more than 256 points (the per-leaf order check would go quadratic) -- and the frame takes the sort path in the same call; either way the arrays
+    are the oracle's.  Also: a 1000-wide frame with many holes (runs of one voxel meet inside one 256-point step: the leaf lists are sorted in place), both leaf orders,
+    and a batch that mixes frames of both kinds."""
+    monkeypatch.setenv("F3DS_VOX_TILES", "2")
+    cases = [("organised, holes", P.synth_frame(0, 21, 1000, 120, 150), dict(voxel_res=0.008, seed_res=0.08)),
+             ("organised, descending leaves", P.synth_frame(0, 22, 640, 200, 30), dict(voxel_res=0.01, seed_res=0.1, leaf_order=1)),
+             ("organised, no transform", P.synth_frame(0, 23, 500, 300, 30), dict(voxel_res=0.02, seed_res=0.2, use_transform=0)),
+             ("dense voxels", P.synth_frame(0, 24, 400, 300, 10), dict(voxel_res=0.08, seed_res=0.4)),
+             ("unorganised cloud", P.synth_frame(1, 3001, 300, 400, 0), dict(voxel_res=0.04, seed_res=0.4, use_transform=0))]
+    for what, pts, kw in cases:
+        prm = P.launch_params(**kw)
+        ctx = P.Context(0)
+        for rep in range(2):      # (the second call of a context that fell back goes straight to the sort path)
+            rc, olab, ores, oh = oracle.segment(pts, prm)
+            assert rc == 0
+            glab = ctx.segment(pts, prm)
+            assert np.array_equal(olab, glab), what
+            for w in ("GRID", "VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_XYZ", "VOXEL_RGB", "POINT_VOXEL", "VOXEL_NEIGHBORS", "VOXEL_NORMAL", "MERGES"):
+                assert first_mismatch(w, oh.get(w), ctx.debug(w)) is None, (what, w)
+        ctx.close()
+    frames = [c[1] for c in cases[:3]] + [cases[4][1], np.zeros((0, 4), np.float32), cases[0][1]]
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.12)
+    ctxs = [P.Context(0) for _ in frames]
+    got = P.segment_batch(ctxs, frames, prm)
+    for f, g in zip(frames, got):
+        rc, olab, _, _ = oracle.segment(f, prm)
+        assert rc == 0 and np.array_equal(olab, g)
+    for c in ctxs:
+        c.close()
 
 
 def test_global_memory_merge_kernel_matches_too(P, oracle, monkeypatch):
