@@ -514,24 +514,28 @@ int seg_vox_tiles(f3ds_ctx* c, int code_bits, int tile_bits) {      // (code_bit
     const uint32_t n = c->n;
     const uint32_t ntiles = (n + VT_TILE - 1u) / VT_TILE;
     const uint64_t dcap64 = (uint64_t)ntiles * VT_ENT_MAX;
-    if (code_bits + tile_bits > 64 || dcap64 > 0x7fffffffull || (uint64_t)ntiles * VT_TAB > 0x7fffffffull) return F3DS_ERR_UNSUPPORTED;      // (the caller takes the sort path)
+    if (code_bits + tile_bits + VT_CNT_BITS > 64 || dcap64 > 0x7fffffffull || (uint64_t)ntiles * VT_TAB > 0x7fffffffull) return F3DS_ERR_UNSUPPORTED;      // (the caller takes the sort path)
     const uint32_t dcap = (uint32_t)dcap64;
     const uint64_t fin = c->h_dc->n_finite;
     const uint32_t capV = (uint32_t)std::max<uint64_t>(256u, std::min<uint64_t>(fin, dcap));
     c->vox_cap = capV;
-    uint64_t *k0, *k1; uint32_t *ploc, *v0, *v1, *cnt_te, *base_te, *ord_te, *vkey, *vcount, *seg_start, *list; float* vf; int* pt_voxel;
+    uint64_t *k0, *k1; uint32_t *ploc, *v0, *v1, *part, *vkey, *vcount, *seg_start, *list; uint2* bo_te; float* vf; int* pt_voxel;
+    const uint32_t nchunks = (dcap + DS_CHUNK - 1u) / DS_CHUNK;
     ENSURE(c->pslot, uint32_t, n, ploc); ENSURE(c->keys0, uint64_t, dcap, k0); ENSURE(c->keys1, uint64_t, dcap, k1); ENSURE(c->vals0, uint32_t, dcap, v0); ENSURE(c->vals1, uint32_t, dcap, v1);
-    ENSURE(c->hcnt, uint32_t, (size_t)ntiles * VT_TAB * 3, cnt_te); base_te = cnt_te + (size_t)ntiles * VT_TAB; ord_te = base_te + (size_t)ntiles * VT_TAB;
+    { uint32_t* w; ENSURE(c->hcnt, uint32_t, (size_t)ntiles * VT_TAB * 2 + 2u * nchunks, w); bo_te = reinterpret_cast<uint2*>(w); part = w + (size_t)ntiles * VT_TAB * 2; }
     ENSURE(c->vkey, uint32_t, (size_t)capV * 3, vkey); ENSURE(c->vcount, uint32_t, capV, vcount); ENSURE(c->vf, float, (size_t)capV * 12, vf);
     ENSURE(c->seg_start, uint32_t, (size_t)capV + 1, seg_start); ENSURE(c->vlist, uint32_t, n, list); ENSURE(c->pt_voxel, int, n, pt_voxel);
     { uint32_t *f, *incl; ENSURE(c->flags, uint32_t, capV, f); ENSURE(c->incl, uint32_t, capV, incl); }      // (the seed stage scans V / C flags through them without asking)
     c->idxbits = -1; c->ks = nullptr; c->vs = nullptr;
-    rec<d_tile_keys>(c, std::min<uint32_t>(ntiles, (uint32_t)g_grid_cap * 8u), 0u, c->d_pts, n, c->fa, (const GridInfo*)c->d_grid, ploc, k0, v0, cnt_te, dcap, tile_bits, c->d_dc);
+    rec<d_tile_keys>(c, std::min<uint32_t>(ntiles, (uint32_t)g_grid_cap * 16u), 0u, c->d_pts, n, c->fa, (const GridInfo*)c->d_grid, ploc, k0, v0, dcap, tile_bits, c->d_dc);
     uint64_t* ks; uint32_t* vs;
-    int rc = radix_sort(c, k0, v0, k1, v1, dcap, code_bits + tile_bits, &ks, &vs, 0, &c->d_dc->seg_count);
+    int rc = radix_sort(c, k0, v0, k1, v1, dcap, code_bits + tile_bits, &ks, &vs, VT_CNT_BITS, &c->d_dc->seg_count);      // (the bits above the count field)
     if (rc) return rc;
-    rec<d_desc_scan>(c, 1u, 0u, (const uint64_t*)ks, (const uint32_t*)vs, (const uint32_t*)cnt_te, dcap, capV, tile_bits, c->fa, (const GridInfo*)c->d_grid, base_te, ord_te, seg_start, vkey, c->d_dc);
-    rec<d_tile_place>(c, std::min<uint32_t>(grid_wide(n, 1024), (uint32_t)g_grid_cap * 4u), 0u, (const uint32_t*)ploc, n, (const uint32_t*)base_te, (const uint32_t*)ord_te, list, pt_voxel, (const DevCounters*)c->d_dc);
+    rec<d_desc_part>(c, nchunks, 0u, (const uint64_t*)ks, dcap, tile_bits, part, (const DevCounters*)c->d_dc);
+    rec<d_desc_offsets>(c, 1u, 0u, part, dcap, capV, seg_start, c->d_dc);
+    rec<d_desc_apply>(c, nchunks, 0u, (const uint64_t*)ks, (const uint32_t*)vs, dcap, capV, tile_bits, c->fa, (const GridInfo*)c->d_grid, (const uint32_t*)part, bo_te,
+                      seg_start, vkey, (const DevCounters*)c->d_dc);
+    rec<d_tile_place>(c, std::min<uint32_t>(ntiles, (uint32_t)g_grid_cap * 16u), 0u, (const uint32_t*)ploc, n, (const uint2*)bo_te, list, pt_voxel, (const DevCounters*)c->d_dc);
     rec<d_voxel_list_accum>(c, std::min<uint32_t>(grid_wide(capV, 256), std::max<uint32_t>(64u, grid_wide(n / 8u, 256))), 0u, c->d_pts, list, (const uint32_t*)seg_start, c->fa, vf, vcount, c->d_dc, capV);
     c->vox_hashed = true;
     return F3DS_OK;

@@ -13,7 +13,7 @@ usage: tools/pmc_summary.py <fetch_dir> <write_dir> <frames_per_batched_launch> 
 import collections, csv, glob, json, re, sys
 fetch_dir, write_dir, nf, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 STREAM = {"d_bbox", "d_keys", "d_radix_hist", "d_radix_scatter", "d_radix_scatter_k", "d_heads", "d_segstart", "d_scan_tiles", "d_scan_add", "d_scan_single",
-          "d_fill_u32", "d_fill_f32", "d_copy_u32", "d_iota", "d_voxel_accum", "d_chunkbox", "d_edge_init", "d_seg_count", "d_seg_write"}
+          "d_fill_u32", "d_fill_f32", "d_copy_u32", "d_iota", "d_voxel_accum", "d_chunkbox", "d_edge_init", "d_seg_count", "d_seg_write", "d_tile_keys", "d_multi_op"}
 def load(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -2,7 +2,7 @@
 # On the GPU box (through gpurun): everything profiles/<tag>_* is built from, into gpurun_out/<tag>_*.
 #   tools/refresh_profiles.sh <tag>
 # Then here: cp the summaries named at the end of this script into profiles/.
-tag=${1:-r4}
+tag=${1:-r5}
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -45,6 +45,6 @@ cd /tmp
 timeout 700 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/${tag}_sqA -- python3 $R/bench.py --groups 1 --batch 192 --steps 2 --warmup 1 --host-io-steps 0 --no-cpu-baseline --skip-latency > $R/gpurun_out/${tag}_sqA.log 2>&1
 timeout 700 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/${tag}_sqB -- python3 $R/bench.py --groups 1 --batch 192 --steps 2 --warmup 1 --host-io-steps 0 --no-cpu-baseline --skip-latency > $R/gpurun_out/${tag}_sqB.log 2>&1
 cd $R
-K="d_normals_t d_sweep_claim d_centroid d_sweep_R d_neighbors d_voxel_gather_accum d_radix_scatter_k d_merge_il_t"
+K="d_normals_t d_sweep_claim d_centroid d_sweep_R d_neighbors d_tile_keys d_tile_place d_voxel_list_accum d_merge_il_t"
 { echo "# pass A: issue / wait split (per launch of 192 frames, largest-grid launches)"; python3 tools/pmc_sq.py /tmp/${tag}_sqA $K; echo "# pass B: LDS"; python3 tools/pmc_sq.py /tmp/${tag}_sqB $K; } > gpurun_out/${tag}_sq_counters.txt 2>&1
 echo "copy to profiles/: ${tag}_bench.json ${tag}_bench_driver_flags.json ${tag}_kernel_stats.csv ${tag}_kernel_stats_isolated.csv ${tag}_timeline.txt ${tag}_sweep_trace.txt ${tag}_pmc_hbm_traffic.json ${tag}_sq_counters.txt ${tag}_config4_*"
