@@ -167,7 +167,9 @@ F3DS_HD float a_helper_dist_row(const SweepView& s, uint32_t g, const float vrow
     return n_voxel_distance(hrow, vrow, s.seed_res, s.w_normal, s.w_color, s.w_spatial);
 }
 #define F3DS_R_STACK 24
-#define F3DS_R_ROUNDS 3        // rounds of the incremental R pass (dirty tiles): two do the work on every frame seen so far, a change
+#ifndef F3DS_R_ROUNDS
+#define F3DS_R_ROUNDS 4        // rounds of the incremental R pass (dirty tiles): two do the work on most frames, but with three the last round still changed a word
+#endif                         // in sweeps 8-10 of some of the 1M-point bench frames and sent them to the chain walker (0.26 ms per launch of 192 frames each); a change
                                // in the last one sends the sweep to the chain walker instead
 #define F3DS_R_PASSES 1        // grid passes of the chain walker; what is still unsettled goes to the single-workgroup tail
 #define F3DS_R_TRUE 1
