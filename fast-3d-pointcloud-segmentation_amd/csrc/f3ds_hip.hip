@@ -549,7 +549,7 @@ int seg_voxels(f3ds_ctx* c) {
         c->hmask = hc2 - 1;
         ENSURE(c->nbr, int, (size_t)V * 27, nbr); ENSURE(c->nbrT, int, (size_t)V * 27, nbrT); ENSURE(c->hkeys, uint64_t, hc2, hkeys); ENSURE(c->hvals, uint32_t, hc2, hvals);
         rec_fill(c, hkeys, 0xFFFFFFFFu, (size_t)hc2 * 8);
-        rec<d_vox_hash>(c, 1u, 0u, (const uint32_t*)c->vkey.p, V, hkeys, hvals, c->hmask);
+        rec<d_vox_hash>(c, 1u, 0u, (const uint32_t*)c->vkey.p, V, (const GridInfo*)c->d_grid, hkeys, hvals, c->hmask);
         rec<d_neighbors>(c, grid_wide((size_t)V * 27, 256), 0u, (const uint32_t*)c->vkey.p, (const DevCounters*)c->d_dc, (const GridInfo*)c->d_grid, (const uint64_t*)hkeys, (const uint32_t*)hvals,
                          c->hmask, nbr, nbrT);
         return F3DS_OK;

@@ -79,6 +79,24 @@ def test_tile_voxelisation_falls_back_where_it_must_and_agrees_everywhere(P, ora
         c.close()
 
 
+@pytest.mark.parametrize("stage0", ["sort", "tiles"])
+def test_deep_grids_take_the_two_word_voxel_table(P, oracle, monkeypatch, stage0):
+    """The voxel table of the neighbour search keeps key and ordinal in one 8-byte word for grids of depth <= 10 (every BASELINE configuration) and falls back to 63-bit keys
+    + a value array beyond: a frame voxelised at 0.5 mm (depth 12) and the same frame at 2 mm (depth 10) against the oracle, neighbour table included."""
+    monkeypatch.setenv("F3DS_VOX_TILES", "2" if stage0 == "tiles" else "0")
+    pts = P.synth_frame(0, 5, 200, 150, 20)
+    ctx = P.Context(0)
+    for vres, depth in ((0.0005, 12), (0.002, 10)):
+        prm = P.launch_params(voxel_res=vres, seed_res=vres * 10)
+        rc, olab, ores, oh = oracle.segment(pts, prm)
+        assert rc == 0 and ores.octree_depth == depth
+        glab = ctx.segment(pts, prm)
+        assert ctx.result.octree_depth == depth and np.array_equal(olab, glab)
+        for w in ("GRID", "VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_NEIGHBORS", "VOXEL_NORMAL", "SEED_KEPT", "VOXEL_SVLABEL", "MERGES"):
+            assert first_mismatch(w, oh.get(w), ctx.debug(w)) is None, (vres, w)
+    ctx.close()
+
+
 def test_global_memory_merge_kernel_matches_too(P, oracle, monkeypatch):
     """d_merge (edges in HBM, used when they do not fit LDS) against the oracle."""
     monkeypatch.setenv("F3DS_FORCE_GLOBAL_MERGE", "1")
