@@ -244,6 +244,36 @@ def test_gpu_merge_only_entry_errors_and_state(oracle, P):
 
 
 @pytest.mark.gpu
+def test_gpu_merge_only_entry_with_more_supervoxels_than_the_lds_kernels_index(oracle, P):
+    """70 000 caller-supplied supervoxels (the list-walking merge kernels pack two 16-bit region indices per word: such a set takes d_merge, everything in global memory),
+    a chain adjacency, arbitrary 32-bit keys: merges and surviving labels equal the oracle's."""
+    rng = np.random.default_rng(11)
+    S = 70000
+    label = (np.cumsum(rng.integers(1, 50000, S).astype(np.uint64)) + 7).astype(np.uint32)
+    cnt = rng.integers(1, 4, S)
+    off = np.zeros(S + 1, np.uint32); off[1:] = np.cumsum(cnt)
+    base = np.repeat(np.arange(S, dtype=np.float32) * 0.05, cnt)
+    xyz = np.stack([base + rng.normal(0, 0.004, len(base)).astype(np.float32), rng.normal(0, 0.01, len(base)).astype(np.float32),
+                    1.0 + rng.normal(0, 0.01, len(base)).astype(np.float32)], axis=1).astype(np.float32)
+    grey = np.repeat(rng.integers(0, 256, S), cnt).astype(np.uint32)
+    rgba = (grey << 16) | (((grey * 7) & 255) << 8) | ((grey * 13) & 255)
+    cent = np.stack([np.arange(S, dtype=np.float32) * 0.05, np.zeros(S, np.float32), np.ones(S, np.float32)], axis=1)
+    nrm = rng.normal(0, 1, (S, 3)).astype(np.float32); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    sv = dict(label=label, voxel_offset=off, voxel_xyz=xyz, voxel_rgba=rgba.astype(np.uint32), centroid_xyz=cent, normal=nrm.astype(np.float32))
+    pairs = np.stack([label[:-1], label[1:]], axis=1)
+    pairs = np.vstack([pairs, pairs[:, ::-1]])                       # both directions, as getSupervoxelAdjacency lists them
+    prm = P.launch_params(threshold=0.08)
+    ctx = P.Context(0)
+    region, vlab = ctx.cluster_supervoxels(sv, pairs, prm)
+    assert ctx.merge_layout() == (0, 0)
+    rc, oregion, ovlab, ores, h = oracle.cluster_supervoxels(sv, pairs, prm)
+    assert rc == 0 and ores.n_merges > 50 and (ctx.result.n_merges, ctx.result.n_regions) == (ores.n_merges, ores.n_regions)
+    assert np.array_equal(region, oregion) and np.array_equal(vlab, ovlab)
+    assert first_mismatch("MERGES", ctx.debug("MERGES"), h.get("MERGES")) is None
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_python_clustering_mirror_takes_a_supervoxel_map(oracle, P):
     """Clustering.set_initialstate(segm, adj) in the reference's own shape (a map of supervoxels + an adjacency multimap), get_currentstate() back."""
     pts, prm, labels, res, h, sv, pairs = oracle_frame(oracle, P, "rgbd_160x120")
