@@ -1182,7 +1182,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     int maxd = 0;
     for (f3ds_ctx* c : b.fr) if (c->h_dc->depth > maxd) maxd = c->h_dc->depth;
     // Stage 0b/0c.  Default: the hash path (only the voxels are sorted).  The sort path (every point's key through a three-pass radix sort) remains for frames with
-    // very dense voxels and behind F3DS_VOX_HASH=0.
+    // very dense voxels, for lone frames (below) and behind F3DS_VOX_TILES=0.
     // (a lone frame takes the sort path: two of the tile path's kernels are one workgroup per frame -- 2.4 ms on a lone frame's critical path, nothing in a batch)
     bool hashed = g_sw.vox_hash && (nctx >= 4 || g_sw.vox_tiles_forced);
     for (f3ds_ctx* c : b.fr) { c->vox_hashed = false; if (c->vox_dense) hashed = false; }
