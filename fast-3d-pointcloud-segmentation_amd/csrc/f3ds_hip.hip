@@ -755,7 +755,7 @@ bool merge_il_layout(uint32_t E, uint32_t S0, int nw, int res, MergeLds* xl) {  
     const MergeIlLayout L = merge_il_offsets(E, nw, res);
     xl->Ecap = L.Ecap; xl->NGcap = L.NGcap; xl->lds_bytes = L.total; xl->keys_in_lds = res;
     xl->spec = g_sw.merge_spec ? 1 : 0;      // (the speculative second merge of an epoch; F3DS_MERGE_SPEC=0 switches it off)
-    return L.total <= 160u * 1024u - 2560u && S0 <= 65534u;      // (2.5 KB: the kernel's static LDS)
+    return L.total <= MC_LDS_LIMIT && S0 <= 65534u;
 }
 // merge kernel of a batch: MK_GLOBAL (d_merge, everything in HBM: any size) or MK_IL + (8 waves ? 0 : 2) + (res == 2 ? 0 : 1)
 enum MergeKind { MK_GLOBAL = 0, MK_IL = 1 };

@@ -447,6 +447,13 @@ def test_every_merge_kernel_layout_gives_the_oracle_merges(P, oracle, monkeypatc
         lab = ctx.segment(P.synth_frame(*e["synth"]), P.launch_params(**e["params"]))
         assert sha_of(lab) == e["labels_sha256"], seed
         assert sha_of(ctx.debug("MERGES")) == e["sha256"]["MERGES"], seed
+    # supervoxels of ~630 voxels (seed / voxel resolution 60): the speculative second merge of the 8-wave layout absorbs regions of up to 1024 rows,
+    # staged in two rounds of one row per lane
+    pts = P.synth_frame(0, 77, 640, 480, 10); prm = P.launch_params(voxel_res=0.005, seed_res=0.3)
+    rc, olab, ores, oh = oracle.segment(pts, prm)
+    assert rc == 0 and ores.n_merges > 100 and ores.n_voxels > 512 * ores.n_supervoxels
+    assert np.array_equal(ctx.segment(pts, prm), olab)
+    assert np.array_equal(ctx.debug("MERGES"), oh.get("MERGES"))
     ctx.close()
 
 
