@@ -324,8 +324,8 @@ class Context:
 
     def segment(self, points, params, labels_out=None, n=None, on_device=False):
         """points: (N,4) float32 ndarray (host) or a device pointer (int) with ``n`` given and
-        ``on_device=True``.  Returns the per-point labels (ndarray) or writes them to the device
-        pointer ``labels_out``."""
+        ``on_device=True``.  Returns the per-point labels (ndarray; ``labels_out`` itself when a host array is given) or writes
+        them to the device pointer ``labels_out``."""
         if on_device:
             ptr, count = ctypes.c_void_p(int(points)), int(n)
             out_ptr = ctypes.c_void_p(int(labels_out)) if labels_out is not None else None
@@ -333,7 +333,12 @@ class Context:
             self._n = count
             return None
         pts = np.ascontiguousarray(points, np.float32).reshape(-1, 4)
-        labels = np.empty(len(pts), np.uint32)
+        if labels_out is None:
+            labels = np.empty(len(pts), np.uint32)
+        else:       # the caller's own buffer (reused from call to call: a fresh 80 MB array for a 20M-point scene is 20 000 page faults inside the download)
+            labels = labels_out
+            if not (isinstance(labels, np.ndarray) and labels.dtype == np.uint32 and labels.flags.c_contiguous and labels.size == len(pts)):
+                raise ValueError("labels_out must be a contiguous uint32 array with one entry per point")
         _check(self.lib, self.lib.f3ds_segment(self.handle, pts.ctypes.data, len(pts), 0, ctypes.byref(params), labels.ctypes.data, 0,
                                                ctypes.byref(self.result)))
         self._n = len(pts)

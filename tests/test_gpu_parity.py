@@ -230,6 +230,13 @@ def test_device_pointers_and_streams(P, oracle, gpu_ctx):
     gpu_ctx.set_stream(0)
     rc, olab, _, _ = oracle.segment(pts, prm)
     assert np.array_equal(d_lab.cpu().numpy().view(np.uint32), olab)
+    # host frames with the caller's own label array (reused from call to call)
+    mine = np.full(len(pts), 0xDEADBEEF, np.uint32)
+    assert gpu_ctx.segment(pts, prm, labels_out=mine) is mine and np.array_equal(mine, olab)
+    with pytest.raises(ValueError):
+        gpu_ctx.segment(pts, prm, labels_out=np.empty(len(pts) + 1, np.uint32))
+    with pytest.raises(ValueError):
+        gpu_ctx.segment(pts, prm, labels_out=np.empty(len(pts), np.int64))
 
 
 def test_cli_on_fixture(P, oracle, tmp_path):
