@@ -192,6 +192,15 @@ def library_stamp(lib=None):
     return text.split("src:")[1].split()[0], text
 
 
+def merge_layout_info(n_edges, waves=8, keys_in_lds=2):
+    """f3ds_merge_layout_info: (dynamic LDS bytes, rows a speculative second merge may absorb, edge slots, fits?) of d_merge_il_t<waves, keys_in_lds>
+    for a frame with n_edges adjacencies.  Host arithmetic only."""
+    out = (ctypes.c_uint32 * 4)()
+    lib = load_library()
+    _check(lib, lib.f3ds_merge_layout_info(ctypes.c_uint32(int(n_edges)), int(waves), int(keys_in_lds), out))
+    return int(out[0]), int(out[1]), int(out[2]), bool(out[3])
+
+
 def check_library_is_current(lib=None):
     """Raise if the loaded libf3ds.so was not built from the sources beside it (a stale prebuilt .so travels to the GPU box with the
     snapshot; measuring or testing it would describe some other code).  Skipped when F3DS_LIB points at another build on purpose."""

@@ -1692,6 +1692,13 @@ extern "C" int f3ds_get_region_adjacency(f3ds_ctx* c, uint32_t* pairs, size_t ca
     return F3DS_OK;
 }
 
+extern "C" int f3ds_merge_layout_info(uint32_t n_edges, int waves, int keys_in_lds, uint32_t out[4]) {
+    if (!out || (waves != 4 && waves != 8) || (keys_in_lds != 0 && keys_in_lds != 2)) return F3DS_ERR_ARG;
+    const MergeIlLayout L = merge_il_offsets(n_edges, waves, keys_in_lds);
+    out[0] = L.total; out[1] = L.sp_rows; out[2] = L.Ecap;
+    out[3] = (L.total <= MC_LDS_LIMIT && (uint64_t)n_edges * (keys_in_lds == 2 ? 10u : 2u) <= (1u << 22)) ? 1u : 0u;
+    return F3DS_OK;
+}
 extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes, size_t* bytes_out) {
     if (!c) return F3DS_ERR_ARG;
     HIPCHECK(hipSetDevice(c->device));

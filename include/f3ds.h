@@ -186,6 +186,11 @@ enum {
                                      LDS, 0 = in global memory).  Diagnostics (bench.py names the kernel it timed): results do not depend on it */
 };
 int f3ds_get_debug(f3ds_ctx* ctx, int what, void* dst, size_t cap_bytes, size_t* bytes_out);
+/* Diagnostics, host arithmetic only (no device needed): the LDS carve-up of the merge kernel d_merge_il_t<waves, keys_in_lds> for a frame with n_edges
+ * adjacencies -- the same function the launch and the kernel use (csrc/f3ds_kernels.inc, merge_il_offsets).  out[0] = dynamic LDS bytes, out[1] = voxel rows the
+ * speculative second merge of an epoch may absorb (128; 256, 512 or 1024 in the 8-wave layout where LDS has room), out[2] = edge slots, out[3] = 1 if the layout fits a
+ * compute unit's LDS (else the cluster stage takes the next layout, at last d_merge).  waves: 4 or 8; keys_in_lds: 2 or 0.  Returns F3DS_ERR_ARG otherwise. */
+int f3ds_merge_layout_info(uint32_t n_edges, int waves, int keys_in_lds, uint32_t out[4]);
 
 /* ---- the VCCS result itself: what main() reads back from pcl::SupervoxelClustering after extract()
  * (src/supervoxel_clustering.cpp:359-367).  All valid after f3ds_segment; call with NULL outputs for the count. */

@@ -22,6 +22,30 @@ def test_every_declared_symbol_is_exported(P):
     assert lib.f3ds_version_string().decode().startswith("f3ds 1.2.0 src:")
 
 
+def test_merge_kernel_lds_layout(P):
+    """The LDS carve-up of d_merge_il_t (host arithmetic shared with the kernel): what fits a compute unit, and how many voxel rows the speculative second merge
+    of an epoch gets -- 128 with four waves; 1024, 512, 256 or 128 with eight, whichever the layout has room for (BASELINE config 4's supervoxels of ~190 voxels need > 128)."""
+    limit = 160 * 1024 - 2560
+    assert P.merge_layout_info(9305, 8, 2)[1] == 512 and P.merge_layout_info(9305, 8, 2)[3]            # the 1M-point bench frame, arrays in LDS
+    assert P.merge_layout_info(25023, 8, 0)[1] == 1024 and P.merge_layout_info(25023, 8, 0)[3]        # config 4, arrays in global memory
+    assert not P.merge_layout_info(25023, 8, 2)[3]                                                      # ... which do not fit LDS
+    last = {}
+    for waves in (4, 8):
+        for res in (0, 2):
+            for e in list(range(0, 2000, 37)) + list(range(2000, 40000, 331)):
+                lds, rows, ecap, fits = P.merge_layout_info(e, waves, res)
+                assert rows in ((128,) if waves == 4 else (128, 256, 512, 1024)) and ecap >= max(e, 64) and ecap % 64 == 0
+                assert fits == (lds <= limit)
+                if waves == 8 and rows > 128:
+                    assert fits                                                   # a bigger second merge never costs the layout its place
+                    assert lds + rows * 52 > limit or rows == 1024      # ... and the next size up would not have fitted
+                prev = last.get((waves, res))
+                assert prev is None or rows <= prev                               # more adjacencies never buy more rows
+                last[(waves, res)] = rows
+    with pytest.raises(P.F3dsError):
+        P.merge_layout_info(100, 6, 2)
+
+
 def test_struct_layout_matches_header(P):
     assert ctypes.sizeof(P.Params) == 14 * 4
     assert ctypes.sizeof(P.Result) == 96          # 92 bytes of fields, 8-byte aligned
