@@ -438,6 +438,8 @@ def main():
         what_if = {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_FAKE_MERGE", "F3DS_FAKE_MERGE_LDS") if os.environ.get(k)}
         if "+whatif" in lib_text:
             what_if["library"] = lib_text
+        if "+dev" in lib_text:      # F3DS_DEV is set: the library reads its development switches (csrc/f3ds_dev.h) -- kernel layouts may differ from production
+            what_if["F3DS_DEV"] = {k: v for k, v in os.environ.items() if k.startswith("F3DS_") and not k.startswith("F3DS_BENCH_")}
         if parity and (parity.get("error") or parity.get("mismatches_all_ranks")):
             invalid = "labels differ from the oracle's committed hashes" if not parity.get("error") else "label check failed: " + parity["error"]
         elif npts == 1000 * 1000 and not (parity and parity.get("frames_checked")):

@@ -21,7 +21,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("F3DS_LIB") or os.path.join(_HERE, "libf3ds.so")       # F3DS_LIB: A/B builds during development
+def _dev_env(name):
+    """A development switch of the environment: only read while F3DS_DEV is set (csrc/f3ds_dev.h; the library applies the same gate)."""
+    return os.environ.get(name) if os.environ.get("F3DS_DEV", "0") not in ("", "0") else None
+
+
+LIB_PATH = _dev_env("F3DS_LIB") or os.path.join(_HERE, "libf3ds.so")       # F3DS_LIB (with F3DS_DEV=1): A/B builds during development
 
 NO_LABEL = 0xFFFFFFFF
 LAB_CIEDE00, RGB_EUCL = 0, 1
@@ -204,7 +209,7 @@ def merge_layout_info(n_edges, waves=8, keys_in_lds=2):
 def check_library_is_current(lib=None):
     """Raise if the loaded libf3ds.so was not built from the sources beside it (a stale prebuilt .so travels to the GPU box with the
     snapshot; measuring or testing it would describe some other code).  Skipped when F3DS_LIB points at another build on purpose."""
-    if os.environ.get("F3DS_LIB"):
+    if _dev_env("F3DS_LIB"):
         return
     have, text = library_stamp(lib)
     want = source_stamp()
@@ -439,9 +444,17 @@ class Context:
         a = {k: np.ascontiguousarray(sv[k], np.float32 if k in ("voxel_xyz", "centroid_xyz", "normal") else np.uint32) for k in
              ("label", "voxel_offset", "voxel_xyz", "voxel_rgba", "centroid_xyz", "normal")}
         S = len(a["label"])
+        # the C entry reads voxel_offset[0..S], voxel_offset[S] voxels and S centroid / normal rows through raw pointers: arrays that disagree with each other
+        # would be read past their end (pack_supervoxels' output is consistent; any other dict is checked here)
+        if a["voxel_offset"].shape != (S + 1,):
+            raise ValueError("voxel_offset must hold n_supervoxels + 1 = %d entries, has shape %s" % (S + 1, a["voxel_offset"].shape))
+        nvox = int(a["voxel_offset"][S])
+        if a["voxel_xyz"].size != 3 * nvox or a["voxel_rgba"].size != nvox:
+            raise ValueError("voxel_xyz / voxel_rgba must hold voxel_offset[-1] = %d voxels (have %d / %d)" % (nvox, a["voxel_xyz"].size // 3, a["voxel_rgba"].size))
+        if a["centroid_xyz"].size != 3 * S or a["normal"].size != 3 * S:
+            raise ValueError("centroid_xyz and normal must have shape (%d, 3)" % S)
         st = SupervoxelSet(S, *[a[k].ctypes.data for k in ("label", "voxel_offset", "voxel_xyz", "voxel_rgba", "centroid_xyz", "normal")])
         pairs = np.ascontiguousarray(adjacency_pairs, np.uint32).reshape(-1, 2)
-        nvox = int(a["voxel_offset"][S]) if S and len(a["voxel_offset"]) > S else 0
         region = np.zeros(S, np.uint32); vlab = np.zeros(nvox, np.uint32)
         _check(self.lib, self.lib.f3ds_cluster_supervoxels(self.handle, ctypes.byref(st), pairs.ctypes.data, len(pairs), ctypes.byref(params), region.ctypes.data,
                                                            vlab.ctypes.data, ctypes.byref(self.result)))
@@ -479,6 +492,12 @@ class Context:
         nb = ctypes.c_size_t(); buf = np.zeros(2, np.uint32)
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, 20, buf.ctypes.data, 8, ctypes.byref(nb)))
         return int(buf[0]), int(buf[1])
+
+    def sweep_stats(self):
+        """(full, incremental, fallback) sweeps of the last run of label-propagation sweeps (F3DS_DBG_SWEEP_STATS)."""
+        nb = ctypes.c_size_t(); buf = np.zeros(3, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 22, buf.ctypes.data, 12, ctypes.byref(nb)))
+        return int(buf[0]), int(buf[1]), int(buf[2])
 
     def tile_list_lengths(self):
         """Length of every 128-voxel tile's one-ring list; 0xFFFFFFFF = the tile overflowed the LDS tables (F3DS_DBG_TILE_LIST_LEN)."""
@@ -839,6 +858,14 @@ class Clustering:
             self._segmented = True
         else:
             self._labels = ctx.recluster(self._params(threshold))
+            if getattr(self, "_user", None):
+                # a later cluster(t) moves the supervoxels to other regions: F3DS_DBG_SV_REGION lists the surviving label per supervoxel in ascending
+                # label order, the caller's rows may be in any order
+                lab = np.asarray(self._user[0]["label"], np.uint32)
+                reg = ctx.debug("SV_REGION")
+                out = np.zeros(len(lab), np.uint32)
+                out[np.argsort(lab, kind="stable")] = reg
+                self._region_of_sv = out
         if self.merging_type == ADAPTIVE_LAMBDA:
             self.lambda_ = ctx.result.lambda_
 
@@ -881,6 +908,25 @@ class Clustering:
     def get_colored_cloud(self):                   # clustering.cpp:631-633 -> (xyz, rgba)
         xyz, _, rgba = self._super.ctx.voxel_cloud()
         return xyz, rgba
+
+    @staticmethod
+    def label2color(xyz, labels):                  # clustering.cpp:793-812 -> (xyz, rgba): the lookup-table colour of every label, opaque alpha
+        labels = np.asarray(labels, np.uint32)
+        table = np.array([label_color(i) for i in range(256)], np.uint32)
+        return np.asarray(xyz, np.float32), (table[labels % 256] | np.uint32(0xFF000000)).astype(np.uint32)
+
+    @staticmethod
+    def color2label(xyz, rgba):                    # clustering.cpp:824-846 -> (xyz, label): one label per distinct colour, numbered in order of first appearance
+        rgba = np.asarray(rgba, np.uint32)
+        uniq, first, inv = np.unique(rgba, return_index=True, return_inverse=True)
+        rank = np.empty(len(uniq), np.uint32)
+        rank[np.argsort(first, kind="stable")] = np.arange(len(uniq), dtype=np.uint32)
+        return np.asarray(xyz, np.float32), rank[inv].astype(np.uint32)
+
+    def get_region_of_supervoxel(self):
+        """After set_initialstate(segm, adj) + cluster(t): label of the region every input supervoxel ended in at the LAST threshold, in the row
+        order of the supervoxel arrays."""
+        return getattr(self, "_region_of_sv", None)
 
     def get_point_labels(self):
         """Per input point region id (the composition with pcl getLabeledCloud); per input VOXEL after

@@ -30,12 +30,14 @@
 #include <string>
 #include <type_traits>
 #include <mutex>
+#include <set>
 #include <vector>
 
 #include "../../include/f3ds.h"
 #include "f3ds_algo.h"
 #include "f3ds_glasbey.h"
 #include "f3ds_eval.h"
+#include "f3ds_dev.h"
 
 using namespace f3ds;
 
@@ -101,7 +103,7 @@ struct Cmd { LaunchFn fn; uint32_t gx, lds, bytes, off; };
 
 // dirty-tile sweeps: a sweep that changed at most V >> shift voxels lets the next one skip clean tiles.
 // F3DS_INC_SHIFT=-1 turns the skipping off (every sweep evaluates every voxel), 32 forces it always.
-const int g_inc_shift = [] { const char* e = getenv("F3DS_INC_SHIFT"); return e ? atoi(e) : 6; }();
+const int g_inc_shift = [] { const char* e = dev_getenv("F3DS_INC_SHIFT"); return e ? atoi(e) : 6; }();
 
 // Development / test switches (none is needed in production and none changes results).  The environment is read ONCE per entry
 // call of the library (f3ds_segment_batch, f3ds_recluster, f3ds_refine_supervoxels) into this per-thread struct -- not per frame on the hot path,
@@ -110,8 +112,8 @@ struct Switches {
     bool direct_labels = false, copy_stream = true, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false, vox_hash = true, vox_tiles_forced = false;
     int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32, r_rounds = F3DS_R_ROUNDS; long relabel_lds_cap = -1;
     void read() {
-        auto on = [](const char* n) { return getenv(n) != nullptr; };
-        auto num = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
+        auto on = [](const char* n) { return dev_getenv(n) != nullptr; };
+        auto num = [](const char* n, long dflt) { const char* e = dev_getenv(n); return e ? atol(e) : dflt; };
         direct_labels = num("F3DS_DIRECT_LABELS", 0) != 0; copy_stream = num("F3DS_COPY_STREAM", 1) != 0; split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
         force_global_merge = on("F3DS_FORCE_GLOBAL_MERGE"); no_stream_pool = on("F3DS_NO_STREAM_POOL"); sort_pairs = on("F3DS_SORT_PAIRS");
         host_prof = on("F3DS_HOST_PROF"); trace_err = on("F3DS_TRACE_ERR");
@@ -119,7 +121,7 @@ struct Switches {
         vox_hash = num("F3DS_VOX_TILES", 1) != 0 && !sort_pairs && !split_voxel_accum;      // (0: stage 0 by sorting the points, as until round 4; the two development switches of that path imply it)
         normals_threads = (int)num("F3DS_NORMALS_THREADS", 0); tile_holes = (uint32_t)num("F3DS_SWEEP_TILE_HOLES", 0);
         { const long v = num("F3DS_MERGE_NW", 0); merge_nw = v == 4 ? 4 : (v ? 8 : 0); }
-        { const char* e = getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
+        { const char* e = dev_getenv("F3DS_MERGE_KEYS"); merge_keys = !e ? -1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "global") ? 1 : 0)); }
         relabel_lds_cap = num("F3DS_RELABEL_LDS_CAP", -1);
         { const long v = num("F3DS_R_ROUNDS_RUN", F3DS_R_ROUNDS); r_rounds = v >= 1 && v <= F3DS_R_ROUNDS ? (uint32_t)v : (uint32_t)F3DS_R_ROUNDS; }
         { const long v = num("F3DS_ILIST_SLACK", 32); ilist_slack = v >= 1 && v <= 32 ? (uint32_t)v : 32u; }      // tests: a short incident-list pool (the merge stage then reruns with a larger one)
@@ -128,7 +130,7 @@ struct Switches {
 thread_local Switches g_sw;
 // where the per-edge arrays of a 4-wave merge loop live when the call shares the device with other batch calls: 0 = global memory (52 KB of LDS per
 // workgroup: two fit a unit, and a voxel-normal workgroup beside them), 2 = LDS (up to 140 KB).  F3DS_MERGE_SHARED_RES=0|2 (A/B runs), read once.
-const int g_merge_shared_res = [] { const char* e = getenv("F3DS_MERGE_SHARED_RES"); return e && atoi(e) == 2 ? 2 : (e && atoi(e) == 0 ? 0 : 0); }();
+const int g_merge_shared_res = [] { const char* e = dev_getenv("F3DS_MERGE_SHARED_RES"); return e && atoi(e) == 2 ? 2 : (e && atoi(e) == 0 ? 0 : 0); }();
 
 }  // namespace
 
@@ -170,7 +172,9 @@ struct f3ds_ctx {
     uint32_t pool_mult = 1;            // leaf pool size factor (grown on demand like ev_mult)
     uint32_t vox_cap = 0;              // bound on the leaves of the current frame that stage 0's tile path sized its buffers by
     bool vox_hashed = false;           // stage 0 of the current frame took the tile path (seg_vox_tiles)
-    bool vox_dense = false;            // this context met a frame the tile path refuses (an unorganised cloud, a voxel of more than VL_MAX_RUN points): its frames take the sort path
+    bool vox_dense = false;            // this context met a frame the tile path refuses (an unorganised cloud, a voxel of more than VL_MAX_RUN points): its frames take the sort path ...
+    uint32_t vox_dense_wait = 0, vox_dense_penalty = 8;      // ... for this many calls, then the tile path is tried again (8, 16, ... 1024 calls after every further refusal): one odd frame
+                                                             // does not cost a long-lived context the faster stage 0 for good
     uint32_t ilist_mult = 1;           // incident-list pool size factor (its own: a leaf-pool overflow must not grow the list pool too)
     uint32_t edge_mult = 32;           // adjacency list room per seed (S0 * edge_mult + 1024), grown on demand
     bool relabel_lds = true;           // stage 6 as one kernel (the region-id table fits LDS for every frame of the batch)
@@ -246,7 +250,7 @@ int ensure(f3ds_ctx* c, Buf& b, size_t count, T** out) {
             return F3DS_ERR_LOGIC;
         }
         g_scratch_allocs.fetch_add(1, std::memory_order_relaxed);
-        static const bool trace = getenv("F3DS_TRACE_ALLOC") != nullptr;
+        static const bool trace = dev_getenv("F3DS_TRACE_ALLOC") != nullptr;
         if (trace && b.p) fprintf(stderr, "f3ds: regrow slot %td: cap %zu, request %zu, mark %zu, pending calls %zu\n", slot, b.cap, bytes, target, c->cmds.size());
         if (b.p) { HIPCHECK(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t want = target + target / 4 + 64;
@@ -290,7 +294,7 @@ thread_local int g_batch_frames = 1;      // frames of the batch call this threa
 std::atomic<int> g_batch_calls[16];
 struct BatchCallCount { int d; explicit BatchCallCount(int dev) : d(dev & 15) { g_batch_calls[d].fetch_add(1, std::memory_order_relaxed); } ~BatchCallCount() { g_batch_calls[d].fetch_sub(1, std::memory_order_relaxed); } };
 size_t grid_cap_for_batch(int frames) {
-    static const size_t target = getenv("F3DS_GRID_TARGET") ? (size_t)atol(getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
+    static const size_t target = dev_getenv("F3DS_GRID_TARGET") ? (size_t)atol(dev_getenv("F3DS_GRID_TARGET")) : 3072;      // with six calls in flight: 24 576: 2 150, 12 288: 2 250, 6 144: 2 280, 3 072 ... 1 024: 2 340 Mpoints/s
     if (!target) return 2048;
     size_t cap = target / (size_t)(frames > 0 ? frames : 1);
     return cap < 8 ? 8 : (cap > 2048 ? 2048 : cap);
@@ -582,7 +586,7 @@ int seg_normals(f3ds_ctx* c) {
     // launch drops from 50-100 ms to 30 ms and the sweeps of the other calls grow by as much (2 140-2 155 vs 2 170 Mpoints/s on one box); alone it is
     // twice as slow (83 vs 43 us per frame: two rounds of long-lived workgroups).  The chip's compute-unit time is conserved; only work removed counts.
 #ifdef F3DS_NORMALS_LOOP
-    static const uint32_t budget = getenv("F3DS_NORMALS_WGS") ? (uint32_t)atoi(getenv("F3DS_NORMALS_WGS")) : 0u;
+    static const uint32_t budget = dev_getenv("F3DS_NORMALS_WGS") ? (uint32_t)atoi(dev_getenv("F3DS_NORMALS_WGS")) : 0u;
 #else
     static const uint32_t budget = 0u;      // (the tile loop is compiled in with make EXTRA=-DF3DS_NORMALS_LOOP only)
 #endif
@@ -856,9 +860,9 @@ int seg_cluster_front(f3ds_ctx* c, const f3ds_params* prm, int kind) {
 // stage 5: the merge loop, one workgroup per frame
 int seg_merge(f3ds_ctx* c) {
 #ifdef F3DS_WHATIF      // make WHATIF=1 only: the stand-in changes the labels, so the default library does not contain it
-    if (const char* e = getenv("F3DS_FAKE_MERGE")) {      // experiment, timing only: see d_fake_merge
+    if (const char* e = dev_getenv("F3DS_FAKE_MERGE")) {      // experiment, timing only: see d_fake_merge
         unsigned us = 30000, waves = 1; sscanf(e, "%u,%u", &us, &waves);
-        const char* l = getenv("F3DS_FAKE_MERGE_LDS");
+        const char* l = dev_getenv("F3DS_FAKE_MERGE_LDS");
         rec<d_fake_merge>(c, 1u, l ? (uint32_t)atoi(l) * 1024u : c->mlds.lds_bytes, c->mdev, (uint32_t)us, (uint32_t)waves);
         return F3DS_OK;
     }
@@ -1060,7 +1064,7 @@ int f3ds_create(int device, f3ds_ctx** out) {
     HIPCHECK(hipSetDevice(device));
     f3ds_ctx* c = new f3ds_ctx;
     c->device = device;
-    if (const char* e = getenv("F3DS_EDGE_MULT")) { const int v = atoi(e); if (v >= 1 && v <= 32) c->edge_mult = (uint32_t)v; }      // tests: start with a short adjacency list
+    if (const char* e = dev_getenv("F3DS_EDGE_MULT")) { const int v = atoi(e); if (v >= 1 && v <= 32) c->edge_mult = (uint32_t)v; }      // tests: start with a short adjacency list
     const int rc = [c]() -> int {
         HIPCHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
@@ -1185,7 +1189,11 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
     // very dense voxels, for lone frames (below) and behind F3DS_VOX_TILES=0.
     // (a lone frame takes the sort path: two of the tile path's kernels are one workgroup per frame -- 2.4 ms on a lone frame's critical path, nothing in a batch)
     bool hashed = g_sw.vox_hash && (nctx >= 4 || g_sw.vox_tiles_forced);
-    for (f3ds_ctx* c : b.fr) { c->vox_hashed = false; if (c->vox_dense) hashed = false; }
+    for (f3ds_ctx* c : b.fr) {
+        c->vox_hashed = false;
+        if (c->vox_dense && hashed) { if (c->vox_dense_wait) c->vox_dense_wait--; else c->vox_dense = false; }      // (counted in calls that would have taken the tile path)
+    }
+    for (f3ds_ctx* c : b.fr) if (c->vox_dense) hashed = false;
     if (hashed) {
         uint32_t maxtiles = 1;
         for (f3ds_ctx* c : b.fr) maxtiles = std::max(maxtiles, (c->n + VT_TILE - 1u) / VT_TILE);
@@ -1198,7 +1206,7 @@ int f3ds_segment_batch(f3ds_ctx** ctxs, int nctx, const void* const* points, con
         if (hashed && g_sw.trace_err) for (f3ds_ctx* c : b.fr) fprintf(stderr, "f3ds: tile path: most voxels in a tile %u, descriptors %u, leaves %u, lists sorted %u\n", c->h_dc->vox_max_tile, c->h_dc->seg_count, c->h_dc->n_voxels, c->h_dc->vox_disorder);
         if (hashed) for (f3ds_ctx* c : b.fr) if (c->h_dc->ev_overflow == 6 || c->h_dc->ev_overflow == 7) {
             if (g_sw.trace_err) fprintf(stderr, "f3ds: tile path refused a frame: %s (descriptors %u, leaves %u)\n", c->h_dc->ev_overflow == 6 ? "a voxel with too many points" : "a tile with too many voxels", c->h_dc->seg_count, c->h_dc->n_voxels);
-            c->vox_dense = true; hashed = false;
+            c->vox_dense = true; c->vox_dense_wait = c->vox_dense_penalty; c->vox_dense_penalty = std::min(2u * c->vox_dense_penalty, 1024u); hashed = false;
         }
         if (!hashed) {
             if (g_sw.trace_err) fprintf(stderr, "f3ds: voxelisation of %zu frames runs again on the sort path (an unorganised cloud or dense voxels)\n", b.fr.size());
@@ -1333,6 +1341,7 @@ int f3ds_cluster_supervoxels(f3ds_ctx* c, const f3ds_supervoxel_set* sv, const u
     std::vector<uint32_t> ea, eb;
     {
         std::vector<std::pair<uint32_t, uint32_t>> ed;      // (h_first, h_second)
+        std::set<std::pair<uint32_t, uint32_t>> seen;
         for (size_t k = 0; k < n_pairs; ++k) {
             const uint32_t p = pairs[2 * k], q = pairs[2 * k + 1];
             if (p > q) continue;
@@ -1343,13 +1352,12 @@ int f3ds_cluster_supervoxels(f3ds_ctx* c, const f3ds_supervoxel_set* sv, const u
                 if (it == lab.end() || *it != l) return F3DS_ERR_OUT_OF_RANGE;
                 hh[w] = (uint32_t)(it - lab.begin());
             }
-            if (hh[0] == hh[1]) return F3DS_ERR_ARG;
+            // (defects are reported in pair order, like the map::at / dereference the reference would meet first: an unknown label of pair k wins over a
+            // duplicate or self-adjacency of a later pair and the other way round -- the oracle checks in the same order)
+            if (hh[0] == hh[1] || !seen.insert({hh[0], hh[1]}).second) return F3DS_ERR_ARG;
             ed.push_back({hh[0], hh[1]});
         }
         std::stable_sort(ed.begin(), ed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
-        std::vector<std::pair<uint32_t, uint32_t>> chk(ed);
-        std::sort(chk.begin(), chk.end());
-        for (size_t k = 1; k < chk.size(); ++k) if (chk[k] == chk[k - 1]) return F3DS_ERR_ARG;
         if (ed.size() > 0x7fffffffull) return F3DS_ERR_UNSUPPORTED;
         ea.resize(ed.size()); eb.resize(ed.size());
         for (size_t k = 0; k < ed.size(); ++k) { ea[k] = ed[k].first; eb[k] = ed[k].second; }
@@ -1712,6 +1720,12 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
     switch (what) {
         case F3DS_DBG_GRID: { HIPCHECK(hipMemcpy(c->h_grid, c->d_grid, sizeof(GridInfo), hipMemcpyDeviceToHost)); double g[5] = {c->h_grid->min[0], c->h_grid->min[1], c->h_grid->min[2], c->h_grid->res, (double)c->h_grid->depth}; put(g, sizeof g); break; }
         case F3DS_DBG_TILE_LIST_LEN: if ((rc = fetch(c, c->tile_n1, (size_t)(V + NT_TILE - 1) / NT_TILE, u))) return rc; put(u.data(), u.size() * 4); break;
+        case F3DS_DBG_SWEEP_STATS: {
+            DevCounters dcs;
+            HIPCHECK(hipMemcpy(&dcs, c->d_dc, sizeof dcs, hipMemcpyDeviceToHost));
+            put(dcs.sweep_stats, 12);
+            break;
+        }
         case F3DS_DBG_MERGE_LAYOUT: { const uint32_t w[2] = {c->merge_kind == MK_GLOBAL ? 0u : (uint32_t)mk_waves(c->merge_kind), c->merge_kind == MK_GLOBAL ? 0u : (uint32_t)mk_res(c->merge_kind)}; put(w, 8); break; }
         case F3DS_DBG_VOXEL_KEYS: if ((rc = fetch(c, c->vkey, (size_t)V * 3, u))) return rc; put(u.data(), u.size() * 4); break;
         case F3DS_DBG_VOXEL_COUNT: if ((rc = fetch(c, c->vcount, V, u))) return rc; put(u.data(), u.size() * 4); break;

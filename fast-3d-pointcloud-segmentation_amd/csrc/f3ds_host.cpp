@@ -14,6 +14,7 @@
 #include "f3ds_glasbey.h"
 #include "f3ds_build_stamp.h"
 #include "f3ds_math.h"
+#include "f3ds_dev.h"
 
 extern "C" {
 
@@ -38,14 +39,18 @@ void f3ds_default_params(f3ds_params* p) {
 }
 
 int f3ds_version(void) { return F3DS_VERSION; }
-// "f3ds <version> src:<stamp>[ +whatif]": the stamp is the hash of the sources this library was built from (csrc/Makefile)
+// "f3ds <version> src:<stamp>[ +whatif][ +dev]": the stamp is the hash of the sources this library was built from (csrc/Makefile);
+// " +dev" = the process has F3DS_DEV set, i.e. the development switches of csrc/f3ds_dev.h are being read (bench.py then reports no value)
 const char* f3ds_version_string(void) {
 #ifdef F3DS_WHATIF
-    return "f3ds 1.2.0 src:" F3DS_BUILD_STAMP " +whatif";
+#define F3DS_VERSION_TEXT "f3ds 1.2.0 src:" F3DS_BUILD_STAMP " +whatif"
 #else
-    return "f3ds 1.2.0 src:" F3DS_BUILD_STAMP;
+#define F3DS_VERSION_TEXT "f3ds 1.2.0 src:" F3DS_BUILD_STAMP
 #endif
+    return f3ds::dev_mode() ? F3DS_VERSION_TEXT " +dev" : F3DS_VERSION_TEXT;
+#undef F3DS_VERSION_TEXT
 }
+int f3ds_dev_mode(void) { return f3ds::dev_mode() ? 1 : 0; }
 
 const char* f3ds_strerror(int code) {
     switch (code) {

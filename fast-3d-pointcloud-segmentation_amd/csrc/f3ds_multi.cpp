@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "../../include/f3ds.h"
+#include "f3ds_dev.h"
 
 namespace {
 
@@ -294,7 +295,7 @@ int f3ds_multi_create(const int* devices, int n_devices, int max_frames_per_devi
     *out = nullptr;
     const int visible = f3ds_device_count();
     if (visible <= 0) return F3DS_ERR_NO_DEVICE;
-    const bool logical = getenv("F3DS_MULTI_LOGICAL") != nullptr;      // tests: several logical devices on one GPU (see the head of this file)
+    const bool logical = f3ds::dev_getenv("F3DS_MULTI_LOGICAL") != nullptr;      // tests: several logical devices on one GPU (see the head of this file)
     if (n_devices <= 0 || (n_devices > visible && !logical) || n_devices > 64 || max_frames_per_device <= 0) return F3DS_ERR_ARG;
     DeviceGuard guard;
     f3ds_multi* m = new f3ds_multi;
@@ -310,7 +311,7 @@ int f3ds_multi_create(const int* devices, int n_devices, int max_frames_per_devi
     }
     // development / single-GPU test boxes: F3DS_MULTI_FORCE_RCCL=1 builds the communicator with one device too and sends the
     // label block through RCCL to itself, so that the library loading and the grouped send/recv are exercised on one GPU
-    if (!logical && (n_devices > 1 || getenv("F3DS_MULTI_FORCE_RCCL"))) {
+    if (!logical && (n_devices > 1 || f3ds::dev_getenv("F3DS_MULTI_FORCE_RCCL"))) {
         if (!g_rccl.load()) { g_multi_error = "librccl not found (F3DS_RCCL_LIB, librccl.so.1, /opt/rocm/lib)"; f3ds_multi_destroy(m); return F3DS_ERR_UNSUPPORTED; }
         std::vector<int> ids;
         for (const PerDevice& p : m->dev) ids.push_back(p.device);

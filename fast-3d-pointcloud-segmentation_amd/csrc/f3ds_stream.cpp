@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/f3ds.h"
+#include "f3ds_dev.h"
 
 namespace {
 enum { FREE = 0, QUEUED, RUNNING, DONE };
@@ -110,7 +111,7 @@ int f3ds_stream_create(int device, int depth, int groups, f3ds_stream** out) {
     f3ds_stream* s = new f3ds_stream;
     s->device = device; s->depth = depth; s->max_batch = (depth + groups - 1) / groups;
     s->slots.resize(depth);
-    if (const char* e = getenv("F3DS_STREAM_LINGER_US")) s->linger_us = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = f3ds::dev_getenv("F3DS_STREAM_LINGER_US")) s->linger_us = atoi(e) > 0 ? atoi(e) : 0;
     for (Slot& sl : s->slots) {
         int rc = f3ds_create(device, &sl.ctx);
         if (rc) { f3ds_stream_destroy(s); return rc; }

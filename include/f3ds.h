@@ -105,8 +105,13 @@ void f3ds_default_params(f3ds_params* p);
 int f3ds_version(void);
 /* "f3ds 1.2.0 src:<16 hex digits>": the digits are the SHA-256 prefix of the sources the library was built from
  * (csrc/Makefile writes it at build time); tests and bench.py compare it with the sources on disk so that a stale
- * prebuilt libf3ds.so fails loudly.  A library built with the timing experiments compiled in ends in " +whatif". */
+ * prebuilt libf3ds.so fails loudly.  A library built with the timing experiments compiled in ends in " +whatif"; a
+ * process whose environment opens the development switches (below) gets " +dev" appended. */
 const char* f3ds_version_string(void);
+/* 1 when F3DS_DEV is set (to anything but "0") in the environment: only then does the library read its development
+ * switches (F3DS_MERGE_NW, F3DS_VOX_TILES, ... -- kernel layouts and test hooks, none changes results).
+ * Without it they are ignored, whatever the environment holds. */
+int f3ds_dev_mode(void);
 const char* f3ds_strerror(int code);
 const char* f3ds_last_hip_error(void);
 
@@ -181,6 +186,9 @@ enum {
     F3DS_DBG_SV_REGION = 19,      /* S u32 surviving label each supervoxel ended in             */
     F3DS_DBG_TILE_LIST_LEN = 21,  /* ceil(V / 128) u32: length of each 128-voxel tile's one-ring list (the LDS tiles of the normals and
                                      the sweeps); 0xFFFFFFFF = the tile did not fit the tables and took the global-memory path.  Diagnostics */
+    F3DS_DBG_SWEEP_STATS = 22,    /* 3 u32: label-propagation sweeps of the last run that evaluated every voxel from their start / only the tiles marked
+                                     dirty (incremental R rounds) / started incremental and fell back to the chain walker because the last R round
+                                     still changed a word.  Diagnostics and tests (the three kinds end in the same bits)                      */
     F3DS_DBG_MERGE_LAYOUT = 20    /* 2 u32: which merge kernel the last cluster stage ran -- waves per frame (4, 8; 0 = d_merge,
                                      everything in global memory) and where it kept the per-edge arrays (2 = order keys + endpoints in
                                      LDS, 0 = in global memory).  Diagnostics (bench.py names the kernel it timed): results do not depend on it */

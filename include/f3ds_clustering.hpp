@@ -212,8 +212,16 @@ public:
             check(f3ds_cluster_supervoxels(user_.ctx, &s, user_.pairs.data(), user_.pairs.size() / 2, &p, user_.region_of_sv.data(), point_labels_.data(), &res_),
                   "f3ds_cluster_supervoxels");
             user_.uploaded = !user_.label.empty();
-        } else
+        } else {
             check(f3ds_recluster(ctx(), &p, point_labels_.data(), 0, &res_), "f3ds_recluster");
+            // a later cluster(t) moves the supervoxels to other regions: get_region_of_supervoxel() follows (F3DS_DBG_SV_REGION = the surviving
+            // label per supervoxel in ascending label order, i.e. the row order of segm)
+            if (have_user_ && !user_.label.empty()) {
+                size_t nb = 0;
+                user_.region_of_sv.assign(user_.label.size(), 0u);
+                check(f3ds_get_debug(ctx(), F3DS_DBG_SV_REGION, user_.region_of_sv.data(), user_.region_of_sv.size() * sizeof(uint32_t), &nb), "f3ds_get_debug");
+            }
+        }
         if (merging_type == ADAPTIVE_LAMBDA) lambda = res_.lambda;
     }
     // all_thresh(ground_truth, start, end, step) (:691-741); truth = one ground-truth label per input point (the PCD `label` field).
@@ -298,6 +306,25 @@ public:
         }
         ret.second = get_current_adjacency();
         return ret;
+    }
+    // label2color / color2label (clustering.h:207-210, clustering.cpp:793-846): a labelled cloud coloured through the lookup table the coloured cloud uses
+    // (f3ds_label_color; opaque alpha), and back -- a label per distinct colour, numbered in order of first appearance.  (The reference keys its map on the
+    // FLOAT view of the packed colour, which is a NaN for alpha 255 and red >= 128 and then never compares equal; here the key is the 32 colour bits.)
+    static ColoredCloud label2color(const LabeledCloud& label_cloud) {
+        ColoredCloud c; c.xyz = label_cloud.xyz; c.rgba.resize(label_cloud.label.size());
+        for (size_t i = 0; i < label_cloud.label.size(); ++i) c.rgba[i] = 0xFF000000u | f3ds_label_color(label_cloud.label[i]);
+        return c;
+    }
+    static LabeledCloud color2label(const ColoredCloud& colored_cloud) {
+        LabeledCloud c; c.xyz = colored_cloud.xyz; c.label.resize(colored_cloud.rgba.size());
+        std::map<uint32_t, uint32_t> mappings;
+        uint32_t next = 0;
+        for (size_t i = 0; i < colored_cloud.rgba.size(); ++i) {
+            const auto it = mappings.find(colored_cloud.rgba[i]);
+            if (it != mappings.end()) c.label[i] = it->second;
+            else { c.label[i] = next; mappings.insert({colored_cloud.rgba[i], next}); next++; }
+        }
+        return c;
     }
     // label of the region every input supervoxel ended in (rows in ascending label = the iteration order of segm); set_initialstate(segm, adj) only
     const std::vector<uint32_t>& get_region_of_supervoxel() const { return user_.region_of_sv; }

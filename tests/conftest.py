@@ -13,6 +13,7 @@ except ImportError:
     torch = None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("F3DS_DEV", "1")      # the tests drive the library's development switches (kernel layouts, test hooks): csrc/f3ds_dev.h reads them only behind this gate
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -189,6 +189,16 @@ int main() {
     c.set_merging(f3ds::EQUALIZATION);
     try { c.set_bins_num(-1); return 16; } catch (const std::invalid_argument&) {}
     try { c.cluster(0.2f); return 17; } catch (const std::logic_error&) {}               // :670-673
+    {   // the two statics (clustering.h:207-210, clustering.cpp:793-846): label -> lookup-table colour, colour -> label in order of first appearance
+        f3ds::LabeledCloud lc; lc.xyz = {0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4}; lc.label = {7, 3, 7, 260, 3};
+        const f3ds::ColoredCloud cc = f3ds::Clustering::label2color(lc);
+        if (cc.xyz != lc.xyz || cc.rgba.size() != 5) return 18;
+        for (size_t i = 0; i < 5; ++i) if (cc.rgba[i] != (0xFF000000u | f3ds_label_color(lc.label[i]))) return 18;
+        if (cc.rgba[3] != (0xFF000000u | f3ds_label_color(4))) return 18;                 // the table has 256 entries: label 260 wraps
+        const f3ds::LabeledCloud back = f3ds::Clustering::color2label(cc);
+        const std::vector<uint32_t> want = {0, 1, 0, 2, 1};
+        if (back.xyz != lc.xyz || back.label != want) return 19;
+    }
     if (f3ds_device_count() < 1) { std::puts("no device: surface only"); return 0; }
     const uint32_t W = 160, H = 120;
     std::vector<f3ds::PointXYZRGBA> pts((size_t)W * H);
@@ -253,3 +263,30 @@ def test_the_pipeline_guard_reports_what_it_is_there_for():
     assert kinds(["\tflat_load_dword v1, v[4:5]", "\ts_waitcnt vmcnt(0)"] + issue + wait(1) + ["\tv_add_f32_e32 v1, v10, v11"]) == []
     assert kinds(["\tflat_load_dword v1, v[4:5]"] + issue + wait(1)) == ["smem"]
     assert kinds(issue + ["\tds_read_b32 v40, v41", "\ts_waitcnt lgkmcnt(1)", "\tv_mov_b32_e32 v1, v13"]) == []      # a compiler-issued LDS read after ours only strengthens the wait
+
+
+def test_development_switches_are_gated_behind_f3ds_dev(P, monkeypatch):
+    """the ~25 result-neutral F3DS_* switches are read only while F3DS_DEV is set (csrc/f3ds_dev.h).  Host side of it:
+    the gate as the library sees it, and the version string that bench.py voids its value on."""
+    lib = P.load_library()
+    lib.f3ds_dev_mode.restype = ctypes.c_int
+    monkeypatch.delenv("F3DS_DEV", raising=False)
+    monkeypatch.setenv("F3DS_MERGE_NW", "8")            # a stray switch alone opens nothing
+    assert lib.f3ds_dev_mode() == 0
+    assert "+dev" not in lib.f3ds_version_string().decode()
+    monkeypatch.setenv("F3DS_DEV", "0")
+    assert lib.f3ds_dev_mode() == 0
+    monkeypatch.setenv("F3DS_DEV", "1")
+    assert lib.f3ds_dev_mode() == 1
+    text = lib.f3ds_version_string().decode()
+    assert text.endswith(" +dev") and P.library_stamp(lib)[0] == P.source_stamp()      # (the stamp still parses with the suffix)
+
+
+def test_python_label2color_color2label(P):
+    """The Python mirror of Clustering::label2color / color2label (clustering.cpp:793-846) agrees with the C++ one's definition."""
+    xyz = np.arange(15, dtype=np.float32).reshape(5, 3)
+    lab = np.array([7, 3, 7, 260, 3], np.uint32)
+    x2, rgba = P.Clustering.label2color(xyz, lab)
+    assert np.array_equal(x2, xyz) and list(rgba) == [0xFF000000 | P.label_color(int(l)) for l in lab]
+    x3, back = P.Clustering.color2label(x2, rgba)
+    assert np.array_equal(x3, xyz) and list(back) == [0, 1, 0, 2, 1]

@@ -97,6 +97,9 @@ def test_oracle_merge_only_entry_error_codes(oracle, P):
     kept = pairs[pairs[:, 0] < pairs[:, 1]]
     assert oracle.cluster_supervoxels(sv, np.vstack([pairs, kept[:1]]), prm)[0] == P.ERR_ARG
     assert oracle.cluster_supervoxels(sv, np.vstack([pairs, [[lo, lo]]]), prm)[0] == P.ERR_ARG
+    # both defects in one input: the one that comes first in the pair list is reported (the GPU entry agrees: test_gpu_merge_only_entry_errors_and_state)
+    assert oracle.cluster_supervoxels(sv, np.vstack([pairs, kept[:1], [[lo, big]]]), prm)[0] == P.ERR_ARG
+    assert oracle.cluster_supervoxels(sv, np.vstack([pairs, [[lo, big]], kept[:1]]), prm)[0] == P.ERR_OUT_OF_RANGE
     bad = dict(sv); bad["voxel_offset"] = sv["voxel_offset"].copy(); bad["voxel_offset"][1] = bad["voxel_offset"][0]
     assert oracle.cluster_supervoxels(bad, pairs, prm)[0] == P.ERR_ARG
     dup = dict(sv); dup["label"] = sv["label"].copy(); dup["label"][1] = dup["label"][0]
@@ -218,9 +221,20 @@ def test_gpu_merge_only_entry_errors_and_state(oracle, P):
         with pytest.raises(P.F3dsError) as e:
             ctx.cluster_supervoxels(sv, bad_pairs, prm)
         assert e.value.code == P.ERR_ARG
+    # a duplicate AND an unknown label: whichever comes first in the pair list is reported, as the oracle does
+    with pytest.raises(P.F3dsError) as e:
+        ctx.cluster_supervoxels(sv, np.vstack([pairs, kept[:1], [[lo, big]]]), prm)
+    assert e.value.code == P.ERR_ARG
+    with pytest.raises(IndexError):
+        ctx.cluster_supervoxels(sv, np.vstack([pairs, [[lo, big]], kept[:1]]), prm)
     bad = dict(sv); bad["voxel_offset"] = sv["voxel_offset"].copy(); bad["voxel_offset"][1] = bad["voxel_offset"][0]
     with pytest.raises(P.F3dsError):
         ctx.cluster_supervoxels(bad, pairs, prm)
+    # arrays that disagree with each other never reach the C entry (it would read past their end)
+    for key, cut in (("voxel_offset", slice(0, -1)), ("voxel_xyz", slice(0, -1)), ("voxel_rgba", slice(0, -1)), ("centroid_xyz", slice(0, -1)), ("normal", slice(1, None))):
+        short = dict(sv); short[key] = sv[key][cut]
+        with pytest.raises(ValueError):
+            ctx.cluster_supervoxels(short, pairs, prm)
     # no adjacency at all: nothing merges, every supervoxel is its own region
     region, vlab = ctx.cluster_supervoxels(sv, np.zeros((0, 2), np.uint32), prm)
     assert np.array_equal(region, sv["label"]) and ctx.result.n_merges == 0 and ctx.result.n_regions == len(sv["label"])
@@ -298,9 +312,17 @@ def test_gpu_python_clustering_mirror_takes_a_supervoxel_map(oracle, P):
     xyz, lab = c.get_labeled_cloud()
     oc = h.voxel_cloud()
     assert bits_equal(xyz, oc[0]) and np.array_equal(lab, oc[1])
+    # get_region_of_supervoxel() follows every cluster(t), not only the first one
+    want_region = h.get("SV_REGION")                     # ascending label = the row order pack_supervoxels gives a dict
+    assert np.array_equal(c.get_region_of_supervoxel(), want_region) and len(set(want_region.tolist())) < len(want_region)
+    c.cluster(0.0)
+    assert np.array_equal(c.get_region_of_supervoxel(), np.sort(sv["label"]))
+    c.cluster(0.2)
+    assert np.array_equal(c.get_region_of_supervoxel(), want_region)
 
 
 ADAPTER_SRC = r'''
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -360,6 +382,10 @@ int main(int argc, char** argv) {
     // a second threshold continues from the same initial state (cluster() again, :670-679)
     c2.cluster(0.0f);
     if (c2.get_currentstate().first.size() != label.size()) return 37;
+    // ... and get_region_of_supervoxel() follows every cluster(t), not only the first (ADVICE r5): nothing is merged at 0, everything is back at 0.2
+    { std::vector<uint32_t> asc(label); std::sort(asc.begin(), asc.end()); if (c2.get_region_of_supervoxel() != asc) return 38; }
+    c2.cluster(0.2f);
+    if (c2.get_region_of_supervoxel() != want_region) return 39;
     // ---- (3) the reference's exceptions on this path
     f3ds::AdjacencyMapT bad = adj; bad.insert({label[0], 0xFFFFFFF0u});
     f3ds::Clustering c3;

@@ -405,6 +405,7 @@ def test_incremental_R_rounds_that_do_not_converge_fall_back_to_the_chain_walker
         "for n in %r:\n"
         "    lab = ctx.segment(case_points(P, n), case_params(P, n))\n"
         "    out[n] = dict(labels=conftest.sha_of(lab), **{w: conftest.sha_of(ctx.debug(w)) for w in ('VOXEL_SVLABEL', 'VOXEL_DIST', 'SV_CENTROID', 'MERGES')})\n"
+        "    out[n]['stats'] = ctx.sweep_stats(); out[n]['sweeps'] = int(ctx.result.sweeps)\n"
         "    r = ctx.refine_supervoxels(2); out[n]['refined'] = conftest.sha_of(r['voxel_label'])\n"
         "print(json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"), names)
     got = {}
@@ -421,6 +422,12 @@ def test_incremental_R_rounds_that_do_not_converge_fall_back_to_the_chain_walker
         for w in ("VOXEL_SVLABEL", "VOXEL_DIST", "SV_CENTROID", "MERGES"):
             assert got[rounds][n][w] == gold[n]["sha256"][w], (n, w, rounds)
         assert got[rounds][n]["refined"] == got[None][n]["refined"], (n, "refineSupervoxels")
+        for k in (rounds, None):      # F3DS_DBG_SWEEP_STATS: every sweep is one of full / incremental / fallback
+            assert sum(got[k][n]["stats"]) == got[k][n]["sweeps"] and got[k][n]["stats"][1] + got[k][n]["stats"][2] > 0, (n, k, got[k][n]["stats"])
+    # the point of the test: the fallback is TAKEN (final hashes alone do not prove that) -- with one round on every case (two rounds settle most small frames)
+    fallbacks = [got[rounds][n]["stats"][2] for n in names]
+    if rounds == "1":
+        assert all(f > 0 for f in fallbacks), fallbacks
 
 
 MERGE_VARIANTS = ([dict(F3DS_MERGE_NW=nw, F3DS_MERGE_KEYS=k) for nw in ("4", "8") for k in ("lds", "global")] + [dict(F3DS_FORCE_GLOBAL_MERGE="1")] +
@@ -945,6 +952,30 @@ def test_relabel_as_two_kernels_matches_too(P, oracle, monkeypatch, cap):
         assert np.array_equal(l, oracle.segment(f, prm)[1])
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_development_switches_are_ignored_without_f3ds_dev(P, oracle, monkeypatch):
+    """VERDICT r5 item 6 on the device: with F3DS_DEV unset a stray F3DS_MERGE_NW / F3DS_MERGE_KEYS / F3DS_FORCE_GLOBAL_MERGE in the environment does not change
+    which merge kernel a lone frame runs (F3DS_DBG_MERGE_LAYOUT); with the gate open the same variables do."""
+    prm = P.launch_params(voxel_res=0.012, seed_res=0.1)
+    pts = P.synth_frame(0, 4100, 200, 150, 30)
+    want = oracle.segment(pts, prm)[1]
+    ctx = P.Context(0)
+    monkeypatch.delenv("F3DS_DEV", raising=False)
+    monkeypatch.setenv("F3DS_MERGE_NW", "4"); monkeypatch.setenv("F3DS_MERGE_KEYS", "global")
+    assert np.array_equal(ctx.segment(pts, prm), want)
+    assert ctx.merge_layout() == (8, 2)
+    monkeypatch.setenv("F3DS_FORCE_GLOBAL_MERGE", "1")
+    assert np.array_equal(ctx.segment(pts, prm), want)
+    assert ctx.merge_layout() == (8, 2)
+    monkeypatch.setenv("F3DS_DEV", "1")
+    assert np.array_equal(ctx.segment(pts, prm), want)
+    assert ctx.merge_layout() == (0, 0)                  # d_merge
+    monkeypatch.delenv("F3DS_FORCE_GLOBAL_MERGE")
+    assert np.array_equal(ctx.segment(pts, prm), want)
+    assert ctx.merge_layout() == (4, 0)
+    ctx.close()
 
 
 @pytest.mark.gpu

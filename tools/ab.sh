@@ -10,6 +10,7 @@
 #   tools/ab.sh hostio                           the host-in / host-out pass with and without the per-device copy stream
 # Output also goes to gpurun_out/ab_<experiment>.log.  Lines: value [Mpoints/s], ms per step, merge launch ms, label mismatches, lone-frame latency, stage ms per call.
 R=$PWD/fast-3d-pointcloud-segmentation_amd
+export F3DS_DEV=1      # A/B runs use the development switches (csrc/f3ds_dev.h): their bench lines carry the rate as what_if_value, never as value
 mkdir -p gpurun_out
 DRV="--gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --host-io-steps 0"
 line() { python3 -c "

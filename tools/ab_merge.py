@@ -19,7 +19,7 @@ libs = [a for a in sys.argv[1:] if not a.isdigit()]; rounds = int(sys.argv[-1]) 
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F3DS_LIB=l)).stdout.strip().splitlines()[-1]
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, F3DS_LIB=l, F3DS_DEV="1")).stdout.strip().splitlines()[-1]
         res[l] += [float(x) for x in out.split()]
 for l in libs:
     v = res[l]

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Merge stage of one 1M-point frame (and of a batch) with every merge kernel layout: device ms of the stage.
 With F3DS_LIB pointing at a `make PROF=1` build the kernels also print their per-phase shader-clock totals."""
+import os as _os; _os.environ.setdefault("F3DS_DEV", "1")      # this tool drives development switches (csrc/f3ds_dev.h)
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

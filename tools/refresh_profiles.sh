@@ -37,8 +37,8 @@ cd $R
 python3 tools/pmc_summary.py /tmp/${tag}_c4pmc_FETCH_SIZE /tmp/${tag}_c4pmc_WRITE_SIZE 1 gpurun_out/${tag}_config4_pmc_hbm_traffic.json 2 > gpurun_out/${tag}_config4_pmc_summary.txt 2>&1
 tail -12 gpurun_out/${tag}_config4_pmc_summary.txt
 if [ -f fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so ]; then
-  F3DS_LIB=$R/fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so python3 tools/lone_frame.py 3 > gpurun_out/${tag}_merge_prof_raw.txt 2>&1
-  F3DS_LIB=$R/fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so python3 tools/config4_frame.py 2 > gpurun_out/${tag}_config4_merge_prof_raw.txt 2>&1
+  F3DS_DEV=1 F3DS_LIB=$R/fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so python3 tools/lone_frame.py 3 > gpurun_out/${tag}_merge_prof_raw.txt 2>&1
+  F3DS_DEV=1 F3DS_LIB=$R/fast-3d-pointcloud-segmentation_amd/libf3ds_prof.so python3 tools/config4_frame.py 2 > gpurun_out/${tag}_config4_merge_prof_raw.txt 2>&1
 fi
 # 6. SQ counters of the wide kernels, one call of 192 frames at a time (rocprofv3 serialises the dispatches it counts): issue / wait split, then LDS
 cd /tmp

@@ -1,4 +1,5 @@
 """(GPU box) stage 0's tile path on the 64 bench frames: most distinct voxels in a tile, descriptors, leaves (printed by the library under F3DS_TRACE_ERR=1)."""
+import os as _os; _os.environ.setdefault("F3DS_DEV", "1")      # this tool drives development switches (csrc/f3ds_dev.h)
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["F3DS_TRACE_ERR"] = "1"
