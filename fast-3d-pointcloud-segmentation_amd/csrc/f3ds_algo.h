@@ -289,6 +289,7 @@ F3DS_HD bool a_eval_R(const SweepView& s, int w, unsigned char* memo, unsigned c
 // lands at or above 0x80000000 - last - 1.  Labels are below 2^30 (f3ds_segment refuses more seeds), so every rejected word reads >= 2^30 = F3DS_NO_NEXT.
 #define F3DS_NO_NEXT 0x40000000u
 F3DS_HD uint32_t a_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+F3DS_HD uint32_t a_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 F3DS_HD uint32_t a_next_label(const uint32_t x[27], uint32_t bias) {
     uint32_t m[9];
     for (int k = 0; k < 9; ++k) m[k] = a_umin(a_umin(x[3 * k] - bias, x[3 * k + 1] - bias), x[3 * k + 2] - bias);
