@@ -493,6 +493,12 @@ class Context:
         _check(self.lib, self.lib.f3ds_get_debug(self.handle, 20, buf.ctypes.data, 8, ctypes.byref(nb)))
         return int(buf[0]), int(buf[1])
 
+    def stage0_path(self):
+        """'tiles' or 'sort': how the last frame was voxelised (F3DS_DBG_STAGE0_PATH)."""
+        nb = ctypes.c_size_t(); buf = np.zeros(1, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 23, buf.ctypes.data, 4, ctypes.byref(nb)))
+        return "tiles" if buf[0] else "sort"
+
     def sweep_stats(self):
         """(full, incremental, fallback) sweeps of the last run of label-propagation sweeps (F3DS_DBG_SWEEP_STATS)."""
         nb = ctypes.c_size_t(); buf = np.zeros(3, np.uint32)

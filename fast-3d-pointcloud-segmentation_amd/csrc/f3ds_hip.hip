@@ -1720,6 +1720,7 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
     switch (what) {
         case F3DS_DBG_GRID: { HIPCHECK(hipMemcpy(c->h_grid, c->d_grid, sizeof(GridInfo), hipMemcpyDeviceToHost)); double g[5] = {c->h_grid->min[0], c->h_grid->min[1], c->h_grid->min[2], c->h_grid->res, (double)c->h_grid->depth}; put(g, sizeof g); break; }
         case F3DS_DBG_TILE_LIST_LEN: if ((rc = fetch(c, c->tile_n1, (size_t)(V + NT_TILE - 1) / NT_TILE, u))) return rc; put(u.data(), u.size() * 4); break;
+        case F3DS_DBG_STAGE0_PATH: { const uint32_t w = c->vox_hashed ? 1u : 0u; put(&w, 4); break; }
         case F3DS_DBG_SWEEP_STATS: {
             DevCounters dcs;
             HIPCHECK(hipMemcpy(&dcs, c->d_dc, sizeof dcs, hipMemcpyDeviceToHost));

@@ -189,6 +189,9 @@ enum {
     F3DS_DBG_SWEEP_STATS = 22,    /* 3 u32: label-propagation sweeps of the last run that evaluated every voxel from their start / only the tiles marked
                                      dirty (incremental R rounds) / started incremental and fell back to the chain walker because the last R round
                                      still changed a word.  Diagnostics and tests (the three kinds end in the same bits)                      */
+    F3DS_DBG_STAGE0_PATH = 23,    /* 1 u32: how the last frame was voxelised -- 1 = the tile path (the points stay where they are, only per-tile voxel
+                                     descriptors are sorted: frames of a batch), 0 = the sort path (every point's key through a radix sort: lone frames,
+                                     unorganised clouds, very dense voxels).  Diagnostics and tests: the two paths give the same bits              */
     F3DS_DBG_MERGE_LAYOUT = 20    /* 2 u32: which merge kernel the last cluster stage ran -- waves per frame (4, 8; 0 = d_merge,
                                      everything in global memory) and where it kept the per-edge arrays (2 = order keys + endpoints in
                                      LDS, 0 = in global memory).  Diagnostics (bench.py names the kernel it timed): results do not depend on it */

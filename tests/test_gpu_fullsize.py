@@ -58,6 +58,26 @@ def test_nyu_scale_frame_matches_oracle(P, oracle, gpu_ctx, stage0, monkeypatch)
     assert not problems, "\n".join(problems)
 
 
+def test_organised_5m_frame_on_stage0s_tile_path(P, monkeypatch):
+    """Stage 0's tile path beyond the bench frame's size: an ORGANISED 2 560 x 2 048 frame (5.2M points, 137 k voxels, -v 0.006 -s 0.06) through
+    the tile path and through the sort path -- stage-0 arrays, normals, supervoxel labels, merges and per-point labels against the oracle's committed hashes
+    (tools/make_golden_big.py, ~40 s of CPU in the build container).  The 20M scene below is unorganised and always falls back to the sort path."""
+    gold = BIG["organised_5m_frame"]
+    pts = P.synth_frame(*gold["synth"])
+    prm = P.launch_params(**gold["params"])
+    ctx = P.Context(0)
+    for mode, want_path in (("2", "tiles"), ("0", "sort")):
+        monkeypatch.setenv("F3DS_VOX_TILES", mode)
+        labels = ctx.segment(pts, prm)
+        assert ctx.stage0_path() == want_path, mode
+        assert {k: getattr(ctx.result, k) for k in SUMMARY} == gold["summary"], mode
+        assert _sha(labels) == gold["labels_sha256"], mode
+        for w, h in gold["sha256"].items():
+            assert _sha(ctx.debug(w)) == h, (mode, w)
+    _invariants(P, pts, labels, ctx.result)
+    ctx.close()
+
+
 def test_20m_scene_properties(P, gpu_ctx):
     pts = P.synth_frame(1, 3000, 5000, 4000, 0)               # BASELINE.md config 4
     prm = P.launch_params(voxel_res=0.02, seed_res=0.2, use_transform=0)

@@ -1290,3 +1290,27 @@ def test_pinned_host_label_buffers_are_written_by_the_kernel_itself(P, oracle, m
             c.close()
         for p in bufs:
             hip.hipHostFree(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["6", "60601"], ["6", "60602", "16"]], ids=["any-ratio", "big-supervoxels"])
+def test_fuzz_mid_size_frames_against_the_oracle(args):
+    """tools/fuzz_gpu_big.py under the driver (until round 6 this evidence was builder-run only): 6 seeded frames of 100k-350k points per mode (the
+    oracle and its refineSupervoxels take 10-15 s per frame on the box; the builder runs hundreds) --
+    any seed / voxel resolution ratio, and ratios >= 16 (supervoxels of hundreds of voxels: the merge loop's wide speculative merges, the wave-wide centroid path) --,
+    random metrics / merging modes / thresholds / leaf orders, every intermediate array and refineSupervoxels against the oracle run on the box."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu_big.py")] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert lines[-1] == "bad 0" and sum(" ok " in l for l in lines) == 6, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_fuzz_degenerate_clouds_against_the_oracle():
+    """tools/fuzz_clouds.py --gpu under the driver: 40 seeded degenerate clouds -- empty, one point, duplicates, lines, planes, NaN / inf,
+    negative z, huge extents -- through the HIP path against the oracle, return codes and every intermediate array."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_clouds.py"), "40", "606", "--gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout.strip().splitlines()[-1], r.stdout[-2000:]

@@ -31,9 +31,19 @@ def run(job):
     return name, e
 
 
+# an ORGANISED frame beyond 1M points (2 560 x 2 048 = 5.2M, -v 0.006 -s 0.06: at most ~1 000 distinct voxels per tile of 4 096 points and 168 points per voxel, inside what the tile path takes): stage 0's tile path at five times the bench frame's size
+ORGANISED_5M = ("organised_5m_frame", (0, 4242, 2560, 2048, 30), dict(voxel_res=0.006, seed_res=0.06),
+                ("GRID", "VOXEL_KEYS", "VOXEL_COUNT", "VOXEL_XYZ", "VOXEL_RGB", "VOXEL_NORMAL", "POINT_VOXEL", "VOXEL_SVLABEL", "MERGES"))
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-organised":      # (adds / refreshes that one entry: ~40 s instead of the whole file's minutes)
+        path = os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json")
+        out = json.load(open(path)); out.update([run(ORGANISED_5M)])
+        json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+        sys.exit(0)
     jobs = [("config5_seed%d" % s, (0, s, 1000, 1000, 30), dict(voxel_res=0.008, seed_res=0.08), ("MERGES", "VOXEL_SVLABEL")) for s in range(1000, 1064)]
     with Pool(8) as pool:
         out = dict(pool.map(run, jobs, chunksize=1))
     out.update([run(("config4_20m_scene", (1, 3000, 5000, 4000, 0), dict(voxel_res=0.02, seed_res=0.2, use_transform=0), ("MERGES", "VOXEL_KEYS", "EDGES", "VOXEL_SVLABEL")))])
+    out.update([run(ORGANISED_5M)])
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "oracle_golden_big.json"), "w"), indent=1, sort_keys=True)
