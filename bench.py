@@ -277,6 +277,40 @@ def main():
                    "concurrent_calls": hgroups,
                    "what": "same loop, frames in pinned host memory, labels delivered to pinned host memory (no RCCL gather in this pass)"}
         mode["host"] = False
+        # What bounds this number: the host link.  Measured here, in the same run (pinned memory, 256 MB per copy): one way alone, and both ways at once on two
+        # streams.  On the boxes of this pool the link moves LESS in total when both directions run at once than one way alone, so queueing every call's uploads
+        # and downloads on one copy stream (the library's schedule, include/f3ds.h) is the best a schedule can do, and 20 MB per frame one copy after the other
+        # is the bound the host-in / host-out rate is to be read against.
+        try:
+            n = 256 << 20
+            hbuf = torch.empty(n, dtype=torch.uint8).pin_memory(); hbuf2 = torch.empty(n, dtype=torch.uint8).pin_memory()
+            dbuf = torch.empty(n, dtype=torch.uint8, device=dev); dbuf2 = torch.empty(n, dtype=torch.uint8, device=dev)
+
+            def rate(fn, reps=4):
+                fn(); torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return reps * n / (time.perf_counter() - t0) / 1e9
+            h2d = rate(lambda: dbuf.copy_(hbuf, non_blocking=True)); d2h = rate(lambda: hbuf.copy_(dbuf, non_blocking=True))
+            s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+            def both():
+                with torch.cuda.stream(s1):
+                    dbuf.copy_(hbuf, non_blocking=True)
+                with torch.cuda.stream(s2):
+                    hbuf2.copy_(dbuf2, non_blocking=True)
+            duplex = rate(both)
+            bytes_in, bytes_out = 16.0 * npts, 4.0 * npts
+            bound = world * npts / (bytes_in / (h2d * 1e9) + bytes_out / (d2h * 1e9)) / 1e6
+            host_io["link_bound"] = {"h2d_GBps": round(h2d, 1), "d2h_GBps": round(d2h, 1), "both_ways_at_once_GBps_each": round(duplex, 1),
+                                     "Mpoints_per_s_if_copies_serialise": round(bound, 1), "fraction_of_bound": round(host_io["value"] / bound, 3),
+                                     "what": "16 B in + 4 B out per point over the measured one-way rates, one copy after the other (one copy stream per device: the "
+                                             "link carries less in total with both directions active than one way alone, so no schedule of the same bytes beats this bound)"}
+            del hbuf, hbuf2, dbuf, dbuf2
+        except Exception as ex:      # noqa (a measurement beside the line: never fails the run)
+            host_io["link_bound"] = {"error": repr(ex)}
 
     # the labels the timed region produced, against the oracle's committed hashes (tests/golden/oracle_golden_big.json, made in the
     # build container by tools/make_golden_big.py): the last step's block holds the frames of seeds 1000 + 64 rank + i.  Every frame of

@@ -500,10 +500,10 @@ class Context:
         return "tiles" if buf[0] else "sort"
 
     def sweep_stats(self):
-        """(full, incremental, fallback) sweeps of the last run of label-propagation sweeps (F3DS_DBG_SWEEP_STATS)."""
-        nb = ctypes.c_size_t(); buf = np.zeros(3, np.uint32)
-        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 22, buf.ctypes.data, 12, ctypes.byref(nb)))
-        return int(buf[0]), int(buf[1]), int(buf[2])
+        """(full, incremental, fallback, skipped) sweeps of the last run of label-propagation sweeps (F3DS_DBG_SWEEP_STATS)."""
+        nb = ctypes.c_size_t(); buf = np.zeros(4, np.uint32)
+        _check(self.lib, self.lib.f3ds_get_debug(self.handle, 22, buf.ctypes.data, 16, ctypes.byref(nb)))
+        return tuple(int(x) for x in buf)
 
     def tile_list_lengths(self):
         """Length of every 128-voxel tile's one-ring list; 0xFFFFFFFF = the tile overflowed the LDS tables (F3DS_DBG_TILE_LIST_LEN)."""

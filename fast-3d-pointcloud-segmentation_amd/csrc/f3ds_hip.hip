@@ -1724,7 +1724,7 @@ extern "C" int f3ds_get_debug(f3ds_ctx* c, int what, void* dst, size_t cap_bytes
         case F3DS_DBG_SWEEP_STATS: {
             DevCounters dcs;
             HIPCHECK(hipMemcpy(&dcs, c->d_dc, sizeof dcs, hipMemcpyDeviceToHost));
-            put(dcs.sweep_stats, 12);
+            put(dcs.sweep_stats, 16);
 #ifdef F3DS_CEN_STATS
             fprintf(stderr, "d_centroid: quads %u, live rows %u, to the wave path: list %u, leaves %u; per quad ndmax %.2f, max leaves %.1f; per row nd %.2f, leaves %.1f\n", dcs.cen_stats[0], dcs.cen_stats[1], dcs.cen_stats[2],
                     dcs.cen_stats[3], dcs.cen_stats[4] / (double)dcs.cen_stats[0], dcs.cen_stats[7] / (double)dcs.cen_stats[0], dcs.cen_stats[5] / (double)dcs.cen_stats[1], dcs.cen_stats[6] / (double)dcs.cen_stats[1]);

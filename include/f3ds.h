@@ -186,9 +186,10 @@ enum {
     F3DS_DBG_SV_REGION = 19,      /* S u32 surviving label each supervoxel ended in             */
     F3DS_DBG_TILE_LIST_LEN = 21,  /* ceil(V / 128) u32: length of each 128-voxel tile's one-ring list (the LDS tiles of the normals and
                                      the sweeps); 0xFFFFFFFF = the tile did not fit the tables and took the global-memory path.  Diagnostics */
-    F3DS_DBG_SWEEP_STATS = 22,    /* 3 u32: label-propagation sweeps of the last run that evaluated every voxel from their start / only the tiles marked
+    F3DS_DBG_SWEEP_STATS = 22,    /* 4 u32: label-propagation sweeps of the last run that evaluated every voxel from their start / only the tiles marked
                                      dirty (incremental R rounds) / started incremental and fell back to the chain walker because the last R round
-                                     still changed a word.  Diagnostics and tests (the three kinds end in the same bits)                      */
+                                     still changed a word / were skipped because the sweep before them had changed nothing (a fixed point: the
+                                     remaining iterations of expandSupervoxels are no-ops).  Diagnostics and tests (all kinds end in the same bits) */
     F3DS_DBG_STAGE0_PATH = 23,    /* 1 u32: how the last frame was voxelised -- 1 = the tile path (the points stay where they are, only per-tile voxel
                                      descriptors are sorted: frames of a batch), 0 = the sort path (every point's key through a radix sort: lone frames,
                                      unorganised clouds, very dense voxels).  Diagnostics and tests: the two paths give the same bits              */
