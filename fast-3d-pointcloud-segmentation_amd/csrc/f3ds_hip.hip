@@ -727,7 +727,8 @@ int seg_supervoxels(f3ds_ctx* c) {
     ENSURE(c->ralive0, unsigned char, S0 + 1, ralive0);
     rec_fill(c, ralive0, 0u, S0 + 1);
     rec_fill(c, rcnt0, 0u, (size_t)(S0 + 1) * 4);
-    rec<d_sv_fill>(c, S0 ? S0 : 1u, 0u, (const float*)c->vf.p, (const uint32_t*)c->owner0.p, S0, (const uint32_t*)c->hlo.p, (const uint32_t*)c->hhi.p, (const int*)c->ghost_vox.p,
+    rec<d_sv_fill>(c, S0 ? (S0 + 3u) / 4u : 1u, 0u,      // (four helpers per workgroup, one per row of its wave)
+                   (const float*)c->vf.p, (const uint32_t*)c->owner0.p, S0, (const uint32_t*)c->hlo.p, (const uint32_t*)c->hhi.p, (const int*)c->ghost_vox.p,
                    (const unsigned char*)c->ghost_active.p, (const uint32_t*)c->hcount.p, (const uint32_t*)loff, (const float*)c->hc.p, rows, row_voxel, racc0, rcnt0, rrec0, ralive0,
                    c->d_dc, (const uint32_t*)c->htiles.p, (const uint32_t*)c->htcnt.p, V);
     const uint32_t ecap = (uint32_t)std::min<uint64_t>((uint64_t)S0 * c->edge_mult + 1024u, 0x7fffffffu);

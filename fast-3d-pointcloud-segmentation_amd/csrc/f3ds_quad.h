@@ -101,19 +101,20 @@ __device__ inline float edge_weight_quad(const MergeParams& p, const float* r1, 
 // n_rgb2lab (f3ds_numerics.h) for a wave whose lane k < 3 holds the mean of colour channel k in `mine` (the other lanes repeat channel 2): the three gamma
 // curves and the three cube roots are evaluated side by side, everything else as there.  Every lane returns L, a, b.
 // Gamma curve and cube root are evaluated for every lane and the linear pieces selected afterwards (same values: no branch, no divergence between the three lanes).
+// (base: the first of the three lanes -- 0 for a wave, 16 r for row r of a wave that holds four colours, one per row; `lane` counts from it)
 template <class MC = m_lit>
-__device__ inline void lab_three_lanes(float mine, int lane, float lab[3], MC mc = MC()) {
+__device__ inline void lab_three_lanes(float mine, int lane, float lab[3], MC mc = MC(), int base = 0) {
     const float v = mine / 255;
     const float gam = (float)m_pow_pos((double)((v + 0.055f) / 1.055f), mc(MC_GAMMA_EXP), mc);
     const float cl = v <= 0.04045f ? v / 12.92f : gam;
-    const float c0 = __shfl(cl, 0, 64), c1 = __shfl(cl, 1, 64), c2 = __shfl(cl, 2, 64);
+    const float c0 = __shfl(cl, base, 64), c1 = __shfl(cl, base + 1, 64), c2 = __shfl(cl, base + 2, 64);
     const float X = (c0 * 0.412453f + c1 * 0.357580f + c2 * 0.180423f) / 0.950456f;
     const float Y = (c0 * 0.212671f + c1 * 0.715160f + c2 * 0.072169f);
     const float Z = (c0 * 0.019334f + c1 * 0.119193f + c2 * 0.950227f) / 1.088754f;
     const float t = lane == 0 ? X : (lane == 1 ? Y : Z);
     const float cb = (float)m_cbrt_pos((double)t, mc);
     const float fl = t > 0.008856f ? cb : 7.787f * t + 16.0f / 116.0f;          // n_lab_f
-    const float fx = __shfl(fl, 0, 64), fy = __shfl(fl, 1, 64), fz = __shfl(fl, 2, 64);
+    const float fx = __shfl(fl, base, 64), fy = __shfl(fl, base + 1, 64), fz = __shfl(fl, base + 2, 64);
     lab[0] = Y > 0.008856f ? 116.0f * fy - 16.0f : 903.3f * Y;
     lab[1] = 500.0f * (fx - fy);
     lab[2] = 200.0f * (fy - fz);
