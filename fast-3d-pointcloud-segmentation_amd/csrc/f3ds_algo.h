@@ -314,6 +314,110 @@ F3DS_HD bool a_has_thief_words(const SweepView& s, int w, uint32_t h, const uint
         if (y >= F3DS_NO_NEXT || g >= h) return false;
     }
 }
+// ---- R through thief masks (round 6).  The pre-pass of a full sweep has the owners of w's 27 neighbours in registers and evaluates the distances d(g, w) of the
+// lower labels g among them anyway: instead of "is there a thief at all" it now leaves, for every voxel it cannot settle, the MASK of the neighbour slots u whose
+// owner g < owner0(w) has d(g, w) < dist0(w).  With it   R(w) = not exists k in mask(w): R(neighbour k of w)   -- the chain walker reads a word and a memo byte per
+// candidate instead of gathering 27 owners, the helpers' centroid rows and w's feature row again (its gathers were the sweeps' third largest bill).
+// x[k] = sweep-start owner of neighbour k (0 for an absent or unowned one), h = w's own owner.  Bit k of the result <=> neighbour k carries a thief.
+F3DS_HD uint32_t a_thief_mask_words(const SweepView& s, int w, uint32_t h, const uint32_t x[27]) {
+    uint32_t y = a_next_label(x, 1u);
+    uint32_t g = y + 1u;
+    if (y >= F3DS_NO_NEXT || g >= h) return 0u;
+    const float dw = s.dist[w];
+    float wrow[12];
+    a_load_row(s.vf + (size_t)w * 12, wrow);
+    uint32_t mask = 0u;
+    for (;;) {
+        if (a_helper_dist_row(s, g, wrow) < dw)
+            for (int k = 0; k < 27; ++k) mask |= (x[k] == g ? 1u : 0u) << k;
+        const uint32_t last = g;
+        y = a_next_label(x, last + 1u);
+        g = y + last + 1u;
+        if (y >= F3DS_NO_NEXT || g >= h) return mask;
+    }
+}
+// the same with the neighbours' owners gathered from global memory (tiles whose one-ring did not fit the LDS tables)
+F3DS_HD uint32_t a_thief_mask(const SweepView& s, int w) {
+    const uint32_t h = s.owner[w];
+    int nu[27]; uint32_t x[27];
+    for (int k = 0; k < 27; ++k) nu[k] = a_nbr(s, w, k);
+    for (int k = 0; k < 27; ++k) {
+        const uint32_t g = s.owner[nu[k] >= 0 ? nu[k] : w];           // unconditional loads, see a_eval_R
+        x[k] = nu[k] >= 0 ? g : 0u;
+    }
+    return a_thief_mask_words(s, w, h, x);
+}
+// The ghost clause of R(w): a lower helper with a ghost leaf on a neighbour of w (or on w) reaches w at its turn whatever became of that leaf's owner -- no
+// recursion.  The pre-pass only FLAGS the few voxels around a ghost leaf (bit 31 of their mask: F3DS_TMASK_GHOST; the flag alone puts a voxel on the walker's list)
+// and the walker evaluates the clause when it first meets such a voxel: in the pre-pass kernel the loop below cost every voxel registers (17 spilled to scratch).
+F3DS_HD bool a_ghost_steals(const SweepView& s, int w, uint32_t h) {
+    const float dw = s.dist[w];
+    for (int k = 0; k < 27; ++k) {
+        const int u = a_nbr(s, w, k);
+        if (u < 0) continue;
+        for (uint32_t gg = s.ghost_head[u]; gg != 0u; gg = s.ghost_next[gg])
+            if (gg < h && a_helper_dist(s, gg, w) < dw) return true;
+    }
+    return false;
+}
+// R(w) from the masks, memoised like a_eval_R (memo byte = (tag << 2) | value): first w's own candidates with scalars only, the explicit stack just when some
+// R(u) is really unknown.  Every voxel that can show up unknown is owned and was not settled by the pre-pass, i.e. it has a mask of its own.
+#define F3DS_TMASK_GHOST 0x80000000u
+F3DS_HD bool a_eval_R_mask(const SweepView& s, int w0, unsigned char* memo, unsigned char tag, const uint32_t* tmask, int* overflow) {
+    const unsigned char T = (unsigned char)(tag << 2);
+    {
+        const unsigned char m0 = memo[w0];
+        if ((m0 & 0xFC) == T && (m0 & 3) != F3DS_R_OPEN) return (m0 & 3) == F3DS_R_TRUE;
+    }
+    uint32_t mask0 = tmask[w0];
+    if (mask0 & F3DS_TMASK_GHOST) {
+        if (a_ghost_steals(s, w0, s.owner[w0])) { memo[w0] = (unsigned char)(T | F3DS_R_FALSE); return false; }
+        mask0 &= ~F3DS_TMASK_GHOST;
+    }
+    bool stolen = false, unknown = false;
+    for (uint32_t m = mask0; m != 0u; m &= m - 1u) {
+        const int u = a_nbr_w(s, w0, (int)__builtin_ctz(m));
+        const unsigned char mu = memo[u];
+        if (mu == (unsigned char)(T | F3DS_R_TRUE)) stolen = true;
+        else if (mu != (unsigned char)(T | F3DS_R_FALSE)) unknown = true;
+    }
+    if (stolen || !unknown) { memo[w0] = (unsigned char)(T | (stolen ? F3DS_R_FALSE : F3DS_R_TRUE)); return !stolen; }
+    int node[F3DS_R_STACK];
+    uint32_t rem[F3DS_R_STACK];
+    int sp = 0;
+    node[0] = w0; rem[0] = mask0;
+    for (;;) {
+        const int w = node[sp];
+        bool pushed = false, st = false;
+        while (rem[sp] != 0u) {
+            const int k = (int)__builtin_ctz(rem[sp]);
+            const int u = a_nbr_w(s, w, k);
+            const unsigned char mu = memo[u];
+            if (mu == (unsigned char)(T | F3DS_R_TRUE)) { st = true; break; }
+            rem[sp] &= rem[sp] - 1u;
+            if (mu == (unsigned char)(T | F3DS_R_FALSE)) continue;
+            if (sp + 1 >= F3DS_R_STACK) { *overflow = 1; return true; }
+            // R(u) still has to be derived: u's bit is gone from w's remaining mask -- when u comes back R-true w is stolen, when it comes back R-false w goes on
+            uint32_t mu_ = tmask[u];
+            if (mu_ & F3DS_TMASK_GHOST) {
+                if (a_ghost_steals(s, u, s.owner[u])) { memo[u] = (unsigned char)(T | F3DS_R_FALSE); continue; }      // (R(u) is false: w goes on)
+                mu_ &= ~F3DS_TMASK_GHOST;
+            }
+            ++sp; node[sp] = u; rem[sp] = mu_;
+            pushed = true;
+            break;
+        }
+        if (pushed) continue;
+        bool r = !st;
+        for (;;) {
+            memo[node[sp]] = (unsigned char)(T | (r ? F3DS_R_TRUE : F3DS_R_FALSE));
+            if (sp == 0) return r;
+            --sp;
+            if (r) { r = false; continue; }   // child still owned -> parent stolen -> R(parent) = false
+            break;                     // child was stolen first -> parent keeps scanning
+        }
+    }
+}
 // One application of the defining equation of R to voxel w, reading the neighbours' R from bit 31 of
 // ownR instead of deriving it: the incremental sweeps (f3ds_kernels.inc, "dirty tiles") iterate this
 // to the fixed point, which is unique because R(w) only depends on R of voxels with a lower owner.

@@ -189,7 +189,7 @@ struct f3ds_ctx {
     Buf loff, rows, row_voxel, racc0, rcnt0, rrec0, ralive0, ehk, ekeys0, ekeys1, evals0, evals1, ea0, eb0;
     Buf ea, eb, ew, eku, ehist, ealive, ev_epoch, ev_key, ev_prev, racc, rcnt, rrec, ralive, rhead, rtail, lnext, parent, markA, markB, tl, merges;
     Buf r_vf, r_owner, r_dist, r_hc, r_hcount, r_hlo, r_hhi, r_gvox, r_gact, r_gdone, r_ghead, r_gnext, r_tl, r_tcnt, r_seed, r_L;      // refineSupervoxels works on copies
-    Buf tstamp, tround, hdirty, htiles, htcnt, vwl, vwl2, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
+    Buf tstamp, tround, hdirty, htiles, htcnt, vwl, vwl2, vtmask, glut, truth_pts, tsum, tcol, tlab, ctab, csize, eroot, eincl;      // ground-truth evaluation
     Buf hcnt, pslot, vlist;      // stage 0, tile path: per (tile, entry) point count / list base / leaf ordinal; per point its (entry, rank in tile); per-leaf point lists
     Buf u_src, u_voff, u_xyz, u_rgba, u_cent, u_nrm;      // f3ds_cluster_supervoxels: the caller's supervoxels as uploaded
     Buf deltas, skeys0, skeys1, svals0, svals1, cdf_hist, cdf, root, rrank, pool, rstart, rnleaf, rcap, tile_n1, tile_ord, tile_slots, ilist, istart, ilen, icap, rincl;      // (rincl stays last: f3ds_destroy walks pts..rincl)
@@ -666,7 +666,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     uint32_t *tiles4, *trr, *hD;
     ENSURE(c->tstamp, uint32_t, (size_t)4 * T, tiles4); ENSURE(c->tround, uint32_t, (size_t)(F3DS_R_ROUNDS - 1) * T, trr); ENSURE(c->hdirty, uint32_t, S0 + 1, hD);
     uint32_t *tl, *tcnt; ENSURE(*sb.htiles, uint32_t, (size_t)(S0 + 1) * HT_CAP, tl); ENSURE(*sb.htcnt, uint32_t, S0 + 1, tcnt);
-    uint32_t *wl, *wl2; ENSURE(c->vwl, uint32_t, V, wl); ENSURE(c->vwl2, uint32_t, V, wl2);
+    uint32_t *wl, *wl2, *tmask; ENSURE(c->vwl, uint32_t, V, wl); ENSURE(c->vwl2, uint32_t, V, wl2); ENSURE(c->vtmask, uint32_t, V, tmask);
     rec_fill(c, tiles4, 0u, (size_t)4 * T * 4);
     rec_fill(c, trr, 0u, (size_t)(F3DS_R_ROUNDS - 1) * T * 4);
     rec_fill(c, hD, 0u, (size_t)(S0 + 1) * 4);
@@ -687,7 +687,7 @@ int seg_sweeps_on(f3ds_ctx* c, const SweepBufs& sb) {
     a.R = R; a.ownR = ownR; a.owner_out = owner0; a.dist_out = dist0;
     a.ghost_done = ghost_done; a.ghost_active = ghost_active; a.ghost_vox = ghost_vox; a.ghost_head = ghost_head; a.ghost_next = ghost_next;
     a.hlo = hlo; a.hhi = hhi; a.hcount = hcount; a.hc = hc; a.dc = c->d_dc; a.S0 = S0;
-    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.wl = wl; a.wl2 = wl2;
+    a.tR0 = tiles4; a.tR1 = tiles4 + T; a.tC0 = tiles4 + 2 * (size_t)T; a.tC1 = tiles4 + 3 * (size_t)T; a.tRr = trr; a.hD = hD; a.T = T; a.tl = tl; a.tcnt = tcnt; a.wl = wl; a.wl2 = wl2; a.tmask = tmask;
     a.thr = g_inc_shift >= 32 ? 0xFFFFFFFFu : (g_inc_shift < 0 ? 0u : V >> g_inc_shift);
     if (!g_sw.sweep_tiles) a.tile_n1 = nullptr;      // development: F3DS_SWEEP_TILES=0 keeps the sweeps on their global-gather path (A/B, tests)
     else a.tile_n1 = (const uint32_t*)c->tile_n1.p;
