@@ -278,9 +278,10 @@ def main():
                    "what": "same loop, frames in pinned host memory, labels delivered to pinned host memory (no RCCL gather in this pass)"}
         mode["host"] = False
         # What bounds this number: the host link.  Measured here, in the same run (pinned memory, 256 MB per copy): one way alone, and both ways at once on two
-        # streams.  On the boxes of this pool the link moves LESS in total when both directions run at once than one way alone, so queueing every call's uploads
-        # and downloads on one copy stream (the library's schedule, include/f3ds.h) is the best a schedule can do, and 20 MB per frame one copy after the other
-        # is the bound the host-in / host-out rate is to be read against.
+        # streams.  The library queues every call's uploads and downloads on ONE copy stream per device (include/f3ds.h): 20 MB per frame one copy after the other is
+        # the bound that schedule is to be read against (`..._if_copies_serialise`); `..._if_both_ways_overlap` is what a schedule that kept both directions busy
+        # could reach at the duplex rate measured beside it (on some boxes of the pool the link carries LESS in total with both directions active than one way alone --
+        # 2 x 16 against 55 GB/s, DESIGN.md 8 --, on others nearly twice as much: the line says which kind this box is).
         try:
             n = 256 << 20
             hbuf = torch.empty(n, dtype=torch.uint8).pin_memory(); hbuf2 = torch.empty(n, dtype=torch.uint8).pin_memory()
@@ -304,10 +305,12 @@ def main():
             duplex = rate(both)
             bytes_in, bytes_out = 16.0 * npts, 4.0 * npts
             bound = world * npts / (bytes_in / (h2d * 1e9) + bytes_out / (d2h * 1e9)) / 1e6
+            bound2 = world * npts / (max(bytes_in, bytes_out) / (duplex * 1e9)) / 1e6
             host_io["link_bound"] = {"h2d_GBps": round(h2d, 1), "d2h_GBps": round(d2h, 1), "both_ways_at_once_GBps_each": round(duplex, 1),
                                      "Mpoints_per_s_if_copies_serialise": round(bound, 1), "fraction_of_bound": round(host_io["value"] / bound, 3),
-                                     "what": "16 B in + 4 B out per point over the measured one-way rates, one copy after the other (one copy stream per device: the "
-                                             "link carries less in total with both directions active than one way alone, so no schedule of the same bytes beats this bound)"}
+                                     "Mpoints_per_s_if_both_ways_overlap": round(bound2, 1),
+                                     "what": "16 B in + 4 B out per point over the link rates measured in this run: one copy after the other at the one-way rates (the library's "
+                                             "schedule: one copy stream per device), and uploads beside downloads at the rate each direction reaches when both are active"}
             del hbuf, hbuf2, dbuf, dbuf2
         except Exception as ex:      # noqa (a measurement beside the line: never fails the run)
             host_io["link_bound"] = {"error": repr(ex)}
