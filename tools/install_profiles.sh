@@ -1,8 +1,8 @@
 #!/bin/bash
 # Here, after `gpurun -- bash tools/refresh_profiles.sh <tag>`: copy the judged summaries from gpurun_out/ into profiles/ (the bench files keep their JSON line only).
-tag=${1:-r5}
+tag=${1:-r6}
 cd "$(dirname "$0")/.." || exit 1
-for f in kernel_stats.csv kernel_stats_isolated.csv timeline.txt sweep_trace.txt pmc_hbm_traffic.json sq_counters.txt config4_kernel_stats.csv config4_pmc_hbm_traffic.json config4_stages.txt; do cp gpurun_out/${tag}_$f profiles/; done
+for f in kernel_stats.csv kernel_stats_isolated.csv timeline.txt sweep_trace.txt pmc_hbm_traffic.json sq_counters.txt mem_pipeline_counters.txt config4_kernel_stats.csv config4_pmc_hbm_traffic.json config4_stages.txt; do cp gpurun_out/${tag}_$f profiles/; done
 for f in bench.json bench_driver_flags.json bench_profiled_run.json; do tail -1 gpurun_out/${tag}_$f > profiles/${tag}_$f; done
 for p in merge_prof config4_merge_prof; do [ -f gpurun_out/${tag}_${p}_raw.txt ] && grep -a "whole loop\|cycles/merge\|argmin phase\|record:\|speculation\|rows class\|touched class" gpurun_out/${tag}_${p}_raw.txt | tail -14 > profiles/${tag}_$p.txt; done
 python3 - "$tag" <<'PY'

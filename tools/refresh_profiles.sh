@@ -2,7 +2,7 @@
 # On the GPU box (through gpurun): everything profiles/<tag>_* is built from, into gpurun_out/<tag>_*.
 #   tools/refresh_profiles.sh <tag>
 # Then here: cp the summaries named at the end of this script into profiles/.
-tag=${1:-r5}
+tag=${1:-r6}
 R="$GRAFT_REPO_ROOT"; cd "$R" || exit 1
 export TMPDIR=/tmp
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -47,4 +47,7 @@ timeout 700 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LD
 cd $R
 K="d_normals_t d_sweep_claim d_centroid d_sweep_R d_neighbors d_tile_keys d_tile_place d_voxel_list_accum d_merge_il_t"
 { echo "# pass A: issue / wait split (per launch of 192 frames, largest-grid launches)"; python3 tools/pmc_sq.py /tmp/${tag}_sqA $K; echo "# pass B: LDS"; python3 tools/pmc_sq.py /tmp/${tag}_sqB $K; } > gpurun_out/${tag}_sq_counters.txt 2>&1
+# 7. memory-pipeline counters of the wide kernels (TA / TCP / TCC), one call of 192 frames at a time
+tools/pmc_mem.sh d_sweep_claim d_sweep_R_first d_sweep_R d_centroid d_normals d_neighbors d_sv_fill d_voxel_list d_tile_keys > gpurun_out/${tag}_pmc_mem_run.log 2>&1
+cp gpurun_out/pmc_mem.txt gpurun_out/${tag}_mem_pipeline_counters.txt
 echo "copy to profiles/: ${tag}_bench.json ${tag}_bench_driver_flags.json ${tag}_kernel_stats.csv ${tag}_kernel_stats_isolated.csv ${tag}_timeline.txt ${tag}_sweep_trace.txt ${tag}_pmc_hbm_traffic.json ${tag}_sq_counters.txt ${tag}_config4_*"
