@@ -472,7 +472,7 @@ def main():
             cpu["frames_parallel"] = {"value": round(FPS * npts / par_s / 1e6, 4) if libm_same else None, "unit": "Mpoints/s", "cores": nthr, "host_cpus": ncores, "seconds": round(par_s, 2),
                                       "sample": "the %d frames of one step, one frame per core on %d threads through oracle/libf3ds_oracle_libm.so (label path only)" % (FPS, nthr)}
         invalid = None
-        what_if = {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_FAKE_MERGE", "F3DS_FAKE_MERGE_LDS") if os.environ.get(k)}
+        what_if = {k: os.environ[k] for k in ("F3DS_BENCH_THRESHOLD", "F3DS_BENCH_PLAN", "F3DS_FAKE_MERGE", "F3DS_FAKE_MERGE_LDS") if os.environ.get(k)}
         if "+whatif" in lib_text:
             what_if["library"] = lib_text
         if "+dev" in lib_text:      # F3DS_DEV is set: the library reads its development switches (csrc/f3ds_dev.h) -- kernel layouts may differ from production

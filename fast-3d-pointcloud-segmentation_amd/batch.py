@@ -76,6 +76,25 @@ def plan_batches(total_frames, max_batch, groups, ramp=False):
     if total_frames <= 0:
         return []
     max_batch, groups = max(1, max_batch), max(1, groups)
+    import os
+    forced = os.environ.get("F3DS_BENCH_PLAN")      # (development, bench.py voids the run: call sizes as "30,60,...,*,...,30" -- "*" = equal calls of <= max_batch for the rest)
+    if forced:
+        parts = forced.split(",")
+        fixed = sum(int(x) for x in parts if x != "*")
+        rest = total_frames - fixed
+        sizes = []
+        for x in parts:
+            if x != "*":
+                sizes.append(int(x))
+            elif rest > 0:
+                calls = -(-rest // max_batch)
+                size, extra = divmod(rest, calls)
+                sizes += [size + (1 if i < extra else 0) for i in range(calls)]
+        if sum(sizes) == total_frames:
+            out, f = [], 0
+            for k in sizes:
+                out.append((f, f + k)); f += k
+            return out
     sizes = []
     if ramp and groups > 1 and total_frames >= 2 * max_batch:
         up = [max(1, -(-max_batch * (g + 1) // groups)) for g in range(groups)]
