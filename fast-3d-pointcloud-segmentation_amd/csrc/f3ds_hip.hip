@@ -109,12 +109,12 @@ const int g_inc_shift = [] { const char* e = dev_getenv("F3DS_INC_SHIFT"); retur
 // call of the library (f3ds_segment_batch, f3ds_recluster, f3ds_refine_supervoxels) into this per-thread struct -- not per frame on the hot path,
 // where hundreds of getenv() scans per call would also race with a setenv from another thread.  Tests still see per-call values.
 struct Switches {
-    bool direct_labels = false, copy_stream = true, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false, vox_hash = true, vox_tiles_forced = false;
+    bool direct_labels = false, copy_stream = true, copy_duplex = false, split_voxel_accum = false, sweep_tiles = true, merge_spec = true, force_global_merge = false, no_stream_pool = false, sort_pairs = false, host_prof = false, trace_err = false, vox_hash = true, vox_tiles_forced = false;
     int normals_threads = 0, merge_nw = 0, merge_keys = -1; uint32_t tile_holes = 0, ilist_slack = 32, r_rounds = F3DS_R_ROUNDS; long relabel_lds_cap = -1;
     void read() {
         auto on = [](const char* n) { return dev_getenv(n) != nullptr; };
         auto num = [](const char* n, long dflt) { const char* e = dev_getenv(n); return e ? atol(e) : dflt; };
-        direct_labels = num("F3DS_DIRECT_LABELS", 0) != 0; copy_stream = num("F3DS_COPY_STREAM", 1) != 0; split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
+        direct_labels = num("F3DS_DIRECT_LABELS", 0) != 0; copy_stream = num("F3DS_COPY_STREAM", 1) != 0; copy_duplex = num("F3DS_COPY_STREAM", 1) == 2; split_voxel_accum = on("F3DS_SPLIT_VOXEL_ACCUM"); sweep_tiles = num("F3DS_SWEEP_TILES", 1) != 0; merge_spec = num("F3DS_MERGE_SPEC", 1) != 0;
         force_global_merge = on("F3DS_FORCE_GLOBAL_MERGE"); no_stream_pool = on("F3DS_NO_STREAM_POOL"); sort_pairs = on("F3DS_SORT_PAIRS");
         host_prof = on("F3DS_HOST_PROF"); trace_err = on("F3DS_TRACE_ERR");
         vox_tiles_forced = num("F3DS_VOX_TILES", 1) == 2;      // (2: also for lone frames -- tests)
@@ -920,9 +920,9 @@ int finish_empty(f3ds_ctx* c, hipStream_t st, uint32_t* point_labels, int labels
 // one call (16 MB per frame) kept meeting the label downloads of another (4 MB per frame).  Through one stream the link carries one copy at a time at full rate.  A call's
 // downloads are queued only once its labels exist (the host thread waits for the event first), so the stream never sits blocked behind unfinished compute.
 struct CopyStream { std::mutex m; hipStream_t s = nullptr; };
-CopyStream g_copy_stream[16];
-hipStream_t copy_stream_of(int device) {
-    CopyStream& c = g_copy_stream[device & 15];
+CopyStream g_copy_stream[16][2];      // [1]: a second stream for the downloads (development: F3DS_COPY_STREAM=2, both directions of the link at once)
+hipStream_t copy_stream_of(int device, int which = 0) {
+    CopyStream& c = g_copy_stream[device & 15][which & 1];
     std::lock_guard<std::mutex> lk(c.m);
     if (!c.s && hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) c.s = nullptr;
     return c.s;
@@ -988,7 +988,7 @@ int run_cluster(Batch& b, const f3ds_params* prm, uint32_t* const* labels_of, co
     {
         bool want = false;
         for (size_t i = 0; i < b.fr.size(); ++i) if (labels_of && labels_of[index_of[i]] && !b.fr[i]->user_labels && b.fr[i]->n) want = true;
-        hipStream_t dl = (want && !labels_on_device && g_sw.copy_stream) ? copy_stream_of(b.fr[0]->device) : nullptr;
+        hipStream_t dl = (want && !labels_on_device && g_sw.copy_stream) ? copy_stream_of(b.fr[0]->device, g_sw.copy_duplex ? 1 : 0) : nullptr;
         if (dl) {      // queued on the copy stream only once the labels exist: that stream must never sit blocked behind unfinished compute
             for (int k = 1; k < 3; ++k) if (!b.owner->ev_copy[k]) HIPCHECK(hipEventCreateWithFlags(&b.owner->ev_copy[k], hipEventDisableTiming));
             HIPCHECK(hipEventRecord(b.owner->ev_copy[1], b.st));
